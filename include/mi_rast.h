@@ -1,0 +1,174 @@
+/*
+ * mi_rast.h -- C-ABI of the MI355X-native differentiable Gaussian-splatting (feature) rasterizer.
+ *
+ * This is the drop-in boundary for the reference's native rasterizer core.  Each entry point
+ * replaces one static method of CudaRasterizer::Rasterizer
+ *   (CF/cuda_rasterizer/rasterizer.h:24-84, DEPTH/cuda_rasterizer/rasterizer.h),
+ * where CF/ = submodules/diff-gaussian-rasterization_contrastive_f/ and
+ * DEPTH/ = submodules/diff-gaussian-rasterization-depth/ of Jumpat/SegAnyGAussians.
+ * The torch glue the reference keeps in rasterize_points.cu (tensor allocation, P==0 short
+ * circuit, M = sh.size(1)) lives in Python on our side (seganygaussians_amd/rasterizer.py).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / C++ types; all data pointers are DEVICE pointers
+ *    (HBM) unless marked [host]; optional inputs are NULL when absent, exactly like the
+ *    reference's "empty tensor -> nullptr" convention (CF/.../__init__.py:196-206).
+ *  - fp32, contiguous; out_color / dL_dpix are CHW; colors_precomp is (P,C); shs is (P,M,3).
+ *  - `channels` is the reference's compile-time NUM_CHANNELS (config.h:15 = 3,
+ *    config_contrastive_f.h:15 = 32); supported: 3, 32, 64 (mi_rast_supported_channels()).
+ *  - `mask != NULL` selects the DEPTH variant (adds out_mask/out_depth, dL_dmask).
+ *  - `stream` is a hipStream_t (0 = null stream).  The library is stateless between calls; all
+ *    memory is owned by the caller; the three opaque buffers have a private layout that is
+ *    self-contained given (P, W, H, R) and may be handed back verbatim to the backward call.
+ *  - every function returns 0 on success; on failure a nonzero code, and mi_rast_last_error()
+ *    (thread-local) holds the message.  MI_RAST_ERR_NON_RGB carries the reference's text
+ *    "For non-RGB, provide precomputed Gaussian colors!" (rasterizer_impl.cu:242-245).
+ */
+#ifndef MI_RAST_H
+#define MI_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_RAST_OK 0
+#define MI_RAST_ERR_INVALID 1    /* bad argument (shape / unsupported channel count) */
+#define MI_RAST_ERR_NON_RGB 2    /* channels != 3 and colors_precomp == NULL          */
+#define MI_RAST_ERR_HIP 3        /* a HIP runtime call or kernel failed               */
+#define MI_RAST_ERR_ALLOC 4      /* a resize callback returned NULL                   */
+
+/* Replaces std::function<char*(size_t)> (CF/rasterize_points.cu:27-33): must return a device
+ * pointer to at least nbytes bytes (256-B aligned), valid until the caller frees it. */
+typedef char* (*mi_rast_resize_fn)(size_t nbytes, void* user);
+
+/* Replaces CudaRasterizer::Rasterizer::forward (CF/cuda_rasterizer/rasterizer_impl.cu:198-336,
+ * declaration rasterizer.h:34-59; DEPTH variant DEPTH/cuda_rasterizer/rasterizer_impl.cu:198-343).
+ * Stages: preprocess -> inclusive scan -> (host reads num_rendered) -> duplicate keys -> radix sort
+ * -> tile ranges -> per-tile alpha blend.  Writes EVERY element of out_color (and out_mask /
+ * out_depth), so the caller need not zero-fill them.  *num_rendered [host] receives R. */
+int mi_rast_forward(
+    mi_rast_resize_fn geometry_buffer, void* geometry_user,
+    mi_rast_resize_fn binning_buffer, void* binning_user,
+    mi_rast_resize_fn image_buffer, void* image_user,
+    int P, int D, int M, int channels,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* opacities,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    const float* mask,      /* DEPTH variant only, else NULL */
+    float* out_color,       /* [channels, H, W] */
+    float* out_mask,        /* [H, W]  (DEPTH variant) */
+    float* out_depth,       /* [H, W]  (DEPTH variant) */
+    int* radii,             /* [P] */
+    int debug,
+    void* stream,
+    int* num_rendered /* [host] */);
+
+/* Replaces CudaRasterizer::Rasterizer::backward (CF/cuda_rasterizer/rasterizer_impl.cu:340-434,
+ * declaration rasterizer.h:61-84; DEPTH variant adds dL_dout_mask / dL_dmask).  All dL_d* outputs
+ * must be zero-initialised by the caller, as RasterizeGaussiansBackwardCUDA does with
+ * torch::zeros (CF/rasterize_points.cu:151-159). */
+int mi_rast_backward(
+    int P, int D, int M, int channels, int R,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* campos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    char* geom_buffer,
+    char* binning_buffer,
+    char* img_buffer,
+    const float* dL_dpix,        /* [channels, H, W] */
+    const float* dL_dout_mask,   /* [H, W] (DEPTH variant) or NULL */
+    float* dL_dmean2D,           /* [P,3] */
+    float* dL_dconic,            /* [P,4] */
+    float* dL_dopacity,          /* [P]   */
+    float* dL_dcolor,            /* [P,channels] */
+    float* dL_dmask,             /* [P] (DEPTH variant) or NULL */
+    float* dL_dmean3D,           /* [P,3] */
+    float* dL_dcov3D,            /* [P,6] */
+    float* dL_dsh,               /* [P,M,3] */
+    float* dL_dscale,            /* [P,3] */
+    float* dL_drot,              /* [P,4] */
+    int debug,
+    void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (CF/cuda_rasterizer/rasterizer_impl.cu:140-153).
+ * present: one byte (0/1) per Gaussian == torch.bool storage. */
+int mi_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                         const float* projmatrix, uint8_t* present, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::mask_forward / mask_backward
+ * (DEPTH/cuda_rasterizer/rasterizer_impl.cu:450-580, 587-635): mask-only render pair. */
+int mi_rast_mask_forward(
+    mi_rast_resize_fn geometry_buffer, void* geometry_user,
+    mi_rast_resize_fn binning_buffer, void* binning_user,
+    mi_rast_resize_fn image_buffer, void* image_user,
+    int P, int width, int height,
+    const float* means3D, const float* opacities, const float* mask,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix,
+    float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_mask, int* radii, int debug, void* stream, int* num_rendered /* [host] */);
+
+int mi_rast_mask_backward(
+    int P, int R, int width, int height,
+    char* geom_buffer, char* binning_buffer, char* img_buffer,
+    const float* dL_dout_mask, float* dL_dmask, int debug, void* stream);
+
+/* ---- introspection (used by the parity tests and bench.py; not part of the reference API) ---- */
+
+const char* mi_rast_last_error(void);
+const char* mi_rast_version(void);
+/* Writes up to n supported channel counts into out, returns how many exist. */
+int mi_rast_supported_channels(int* out, int n);
+/* Reference helper getHigherMsb (CF/cuda_rasterizer/rasterizer_impl.cu:35-50), host side. */
+uint32_t mi_rast_get_higher_msb(uint32_t n);
+
+/* Private-layout maps of the three opaque buffers, so tests can compare the integer path
+ * bit-exactly with the oracle.  Each call fills `offsets` (bytes from the buffer start) for the
+ * fields listed, and returns the total size in bytes. */
+enum { MI_GEOM_DEPTHS = 0, MI_GEOM_MEANS2D, MI_GEOM_CONIC_OPACITY, MI_GEOM_COV3D, MI_GEOM_RGB,
+       MI_GEOM_CLAMPED, MI_GEOM_TILES_TOUCHED, MI_GEOM_POINT_OFFSETS, MI_GEOM_SCAN_TEMP, MI_GEOM_NFIELDS };
+enum { MI_IMG_FINAL_T = 0, MI_IMG_N_CONTRIB, MI_IMG_RANGES, MI_IMG_TILE_CONSUMED, MI_IMG_NFIELDS };
+enum { MI_BIN_KEYS_UNSORTED = 0, MI_BIN_KEYS, MI_BIN_VALUES_UNSORTED, MI_BIN_POINT_LIST, MI_BIN_SORT_TEMP,
+       MI_BIN_NFIELDS };
+size_t mi_rast_geometry_layout(int P, size_t* offsets /* [MI_GEOM_NFIELDS] */);
+size_t mi_rast_image_layout(int width, int height, size_t* offsets /* [MI_IMG_NFIELDS] */);
+size_t mi_rast_binning_layout(int R, size_t* offsets /* [MI_BIN_NFIELDS] */);
+
+/* Per-stage HIP-event timing on the caller's stream (bench.py's live roofline measurement).
+ * When enabled, forward/backward record events between stages; mi_rast_profile_read synchronises
+ * the last call's events and returns elapsed milliseconds per stage. */
+enum { MI_STAGE_PREPROCESS = 0, MI_STAGE_SCAN, MI_STAGE_DUPLICATE, MI_STAGE_SORT, MI_STAGE_RANGES,
+       MI_STAGE_BLEND_FWD, MI_STAGE_BLEND_BWD, MI_STAGE_GEOM_BWD, MI_STAGE_COUNT };
+int mi_rast_profile_enable(int on);
+int mi_rast_profile_read(float* ms /* [MI_STAGE_COUNT] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,111 @@
+"""ctypes binding of the C-ABI library (include/mi_rast.h).  Fails loudly when the HIP extension is
+missing: there is NO CPU / PyTorch fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+
+MI_GEOM_FIELDS = ["depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped", "tiles_touched",
+                  "point_offsets", "scan_temp"]
+MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed"]
+MI_BIN_FIELDS = ["keys_unsorted", "keys", "values_unsorted", "point_list", "sort_temp"]
+MI_STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "blend_fwd", "blend_bwd", "geom_bwd"]
+
+EXPORTS = [
+    "mi_rast_forward", "mi_rast_backward", "mi_rast_mark_visible", "mi_rast_mask_forward",
+    "mi_rast_mask_backward", "mi_rast_last_error", "mi_rast_version", "mi_rast_supported_channels",
+    "mi_rast_get_higher_msb", "mi_rast_geometry_layout", "mi_rast_image_layout", "mi_rast_binning_layout",
+    "mi_rast_profile_enable", "mi_rast_profile_read",
+]
+
+_lib = None
+
+
+class MiRastError(RuntimeError):
+    pass
+
+
+def load():
+    """Returns the loaded library; raises MiRastError if libmi_rast.so is absent or unloadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MiRastError(
+            f"HIP extension {LIB_PATH} is missing. Build it with `python -m seganygaussians_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise MiRastError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    L.mi_rast_forward.restype = i
+    L.mi_rast_forward.argtypes = [RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, i, i, i, i, vp, i, i,
+                                  vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, i,
+                                  vp, vp, vp, vp, vp, i, vp, C.POINTER(i)]
+    L.mi_rast_backward.restype = i
+    L.mi_rast_backward.argtypes = [i, i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f,
+                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
+    L.mi_rast_mark_visible.restype = i
+    L.mi_rast_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
+    L.mi_rast_mask_forward.restype = i
+    L.mi_rast_mask_forward.argtypes = [RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, i, i, i, vp, vp, vp, vp, f,
+                                       vp, vp, vp, vp, f, f, i, vp, vp, i, vp, C.POINTER(i)]
+    L.mi_rast_mask_backward.restype = i
+    L.mi_rast_mask_backward.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, i, vp]
+    L.mi_rast_last_error.restype = C.c_char_p
+    L.mi_rast_version.restype = C.c_char_p
+    L.mi_rast_supported_channels.restype = i
+    L.mi_rast_supported_channels.argtypes = [C.POINTER(i), i]
+    L.mi_rast_get_higher_msb.restype = C.c_uint32
+    L.mi_rast_get_higher_msb.argtypes = [C.c_uint32]
+    for name, n in (("mi_rast_geometry_layout", 1), ("mi_rast_binning_layout", 1)):
+        fn = getattr(L, name)
+        fn.restype = C.c_size_t
+        fn.argtypes = [i, C.POINTER(C.c_size_t)]
+    L.mi_rast_image_layout.restype = C.c_size_t
+    L.mi_rast_image_layout.argtypes = [i, i, C.POINTER(C.c_size_t)]
+    L.mi_rast_profile_enable.restype = i
+    L.mi_rast_profile_enable.argtypes = [i]
+    L.mi_rast_profile_read.restype = i
+    L.mi_rast_profile_read.argtypes = [C.POINTER(f)]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().mi_rast_last_error().decode("utf-8", "replace")
+
+
+def geometry_layout(P: int):
+    off = (C.c_size_t * len(MI_GEOM_FIELDS))()
+    total = load().mi_rast_geometry_layout(int(P), off)
+    return int(total), dict(zip(MI_GEOM_FIELDS, [int(o) for o in off]))
+
+
+def image_layout(W: int, H: int):
+    off = (C.c_size_t * len(MI_IMG_FIELDS))()
+    total = load().mi_rast_image_layout(int(W), int(H), off)
+    return int(total), dict(zip(MI_IMG_FIELDS, [int(o) for o in off]))
+
+
+def binning_layout(R: int):
+    off = (C.c_size_t * len(MI_BIN_FIELDS))()
+    total = load().mi_rast_binning_layout(int(R), off)
+    return int(total), dict(zip(MI_BIN_FIELDS, [int(o) for o in off]))
+
+
+def profile_enable(on: bool) -> None:
+    if load().mi_rast_profile_enable(1 if on else 0) != 0:
+        raise MiRastError(last_error())
+
+
+def profile_read() -> dict:
+    ms = (C.c_float * len(MI_STAGES))()
+    if load().mi_rast_profile_read(ms) != 0:
+        raise MiRastError(last_error())
+    return dict(zip(MI_STAGES, [float(x) for x in ms]))

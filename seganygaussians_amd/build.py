@@ -1,0 +1,51 @@
+"""Builds the HIP C-ABI library in-tree (seganygaussians_amd/libmi_rast.so) with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting
+.so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_rast.so")
+SRC_DIR = os.path.join(_HERE, "csrc")
+SOURCES = ["mi_rast.hip", "common.h", "geometry.h", "binning.h", "blend_fwd.h", "blend_bwd.h"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "mi_rast.h")
+
+# -ffp-contract=off is part of the numeric contract: the geometry path that feeds the
+# integer tile/sort results must round every binary32 op separately, like the oracle.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
+               "-fPIC", "-shared", "-Wno-unused-result"]
+
+
+def find_hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(SRC_DIR, s) for s in SOURCES] + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp", os.path.join(SRC_DIR, "mi_rast.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

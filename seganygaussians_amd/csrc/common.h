@@ -1,0 +1,133 @@
+// common.h -- shared device helpers for the gfx950 rasterizer kernels.
+//
+// Numeric contract: the per-Gaussian geometry path that feeds the INTEGER results
+// (radii, tile rects, tiles_touched, depth key bits) is IEEE binary32 in the reference's source
+// order with NO fused contraction: this translation unit is compiled with -ffp-contract=off and
+// uses fmaf() only inside the blend kernels' accumulators, which are float-path (tolerance)
+// quantities.  Division and sqrt are correctly rounded (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mirast {
+
+constexpr int TILE_X = 16;  // CF/cuda_rasterizer/config_contrastive_f.h:16 -- part of the integer contract
+constexpr int TILE_Y = 16;  // CF/cuda_rasterizer/config_contrastive_f.h:17
+constexpr int TILE_PIXELS = TILE_X * TILE_Y;
+constexpr int WAVE = 64;
+
+struct Mat3 {  // glm layout m[col][row]
+    float m[3][3];
+};
+
+// glm::mat3 * glm::mat3 (CF/third_party/glm/glm/detail/type_mat3x3.inl:486-520): three products
+// summed left to right.
+__device__ __forceinline__ Mat3 m3mul(const Mat3& A, const Mat3& B)
+{
+    Mat3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+    return R;
+}
+__device__ __forceinline__ Mat3 m3transpose(const Mat3& A)
+{
+    Mat3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+    return R;
+}
+
+// float -> int32: v_cvt_i32_f32 saturates and maps NaN to 0, the same as nvcc's cvt.rzi.s32.f32.
+__device__ __forceinline__ int f2i(float f) { return (int)f; }
+
+// CF/cuda_rasterizer/auxiliary.h:41-44 -- double literals: evaluated in binary64, rounded once.
+__device__ __forceinline__ float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// CF/cuda_rasterizer/auxiliary.h:46-56
+__device__ __forceinline__ void getRect(float px, float py, int max_radius, uint2& rect_min, uint2& rect_max,
+                                        uint32_t gx, uint32_t gy)
+{
+    rect_min.x = min(gx, (uint32_t)max(0, f2i((px - (float)max_radius) / (float)TILE_X)));
+    rect_min.y = min(gy, (uint32_t)max(0, f2i((py - (float)max_radius) / (float)TILE_Y)));
+    rect_max.x = min(gx, (uint32_t)max(0, f2i((px + (float)max_radius + (float)TILE_X - (float)1) / (float)TILE_X)));
+    rect_max.y = min(gy, (uint32_t)max(0, f2i((py + (float)max_radius + (float)TILE_Y - (float)1) / (float)TILE_Y)));
+}
+
+// CF/cuda_rasterizer/auxiliary.h:58-77
+__device__ __forceinline__ float3 transformPoint4x3(const float3& p, const float* m)
+{
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 transformPoint4x4(const float3& p, const float* m)
+{
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
+                       m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+// CF/cuda_rasterizer/auxiliary.h:89-97
+__device__ __forceinline__ float3 transformVec4x3Transpose(const float3& p, const float* m)
+{
+    return make_float3(m[0] * p.x + m[1] * p.y + m[2] * p.z,
+                       m[4] * p.x + m[5] * p.y + m[6] * p.z,
+                       m[8] * p.x + m[9] * p.y + m[10] * p.z);
+}
+// CF/cuda_rasterizer/auxiliary.h:107-117
+__device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv)
+{
+    float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    float3 r;
+    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return r;
+}
+
+// Per-view constants every kernel needs, passed by value (kernarg -> SGPRs).  The 4x4 matrices and the
+// camera position stay in device memory exactly as the reference passes them; every thread reads them
+// at wave-uniform addresses, which gfx950 serves with scalar loads (s_load_dwordx16) from the scalar
+// cache -- no host round trip.
+struct ViewParams {
+    const float* view;    // [16] world->view, column-major for the kernels (scene/cameras.py:62)
+    const float* proj;    // [16] full projection
+    const float* campos;  // [3] or nullptr
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    int W, H;
+    uint32_t grid_x, grid_y;
+};
+
+// ---- wave64 helpers -------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 64 lanes of a wave; the result is valid in EVERY lane.
+// quad_perm xor1 / xor2, row_half_mirror, row_mirror stay inside a 16-lane DPP row (VALU, no LDS);
+// the two cross-row steps use ds_swizzle-free __shfl_xor (ds_bpermute).
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+}  // namespace mirast

@@ -1,0 +1,530 @@
+// mi_rast.hip -- C-ABI implementation (include/mi_rast.h) and host orchestration of the gfx950
+// rasterizer kernels.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
+// -munsafe-fp-atomics -fPIC -shared (see seganygaussians_amd/build.py).  No torch, no pybind.
+#include "../../include/mi_rast.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "binning.h"
+#include "blend_bwd.h"
+#include "blend_fwd.h"
+#include "common.h"
+#include "geometry.h"
+
+using namespace mirast;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(MI_RAST_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+// Mirrors CHECK_CUDA (CF/cuda_rasterizer/auxiliary.h:166-173): with debug set, synchronise after each
+// stage and surface the error; without it only launch errors are caught.
+#define STAGE_CHECK(name)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = hipGetLastError();                                                             \
+        if (_e == hipSuccess && debug) _e = hipStreamSynchronize(stream);                              \
+        if (_e != hipSuccess)                                                                          \
+            return fail(MI_RAST_ERR_HIP, std::string("[HIP ERROR] in stage ") + name + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) & ~(ALIGN - 1); }
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes)
+    {
+        size_t o = off;
+        off = align_up(off + bytes);
+        return o;
+    }
+};
+
+size_t scan_temp_bytes(int P)
+{
+    size_t n = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, n, (uint32_t*)nullptr, (uint32_t*)nullptr, P > 0 ? P : 1);
+    return n;
+}
+size_t sort_temp_bytes(int R)
+{
+    size_t n = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, n, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                       (uint32_t*)nullptr, R > 0 ? R : 1);
+    return n;
+}
+
+// ---- per-stage profiling (bench.py) -----------------------------------------------------------
+bool g_profile = false;
+hipEvent_t g_ev[MI_STAGE_COUNT][2];
+bool g_ev_created = false;
+bool g_ev_used[MI_STAGE_COUNT];
+
+struct StageTimer {
+    hipStream_t s;
+    int stage;
+    StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_)
+    {
+        if (g_profile) (void)hipEventRecord(g_ev[stage][0], s);
+    }
+    ~StageTimer()
+    {
+        if (g_profile) {
+            (void)hipEventRecord(g_ev[stage][1], s);
+            g_ev_used[stage] = true;
+        }
+    }
+};
+
+ViewParams make_view(const float* view_d, const float* proj_d, const float* campos_d, float tan_fovx, float tan_fovy,
+                     float scale_modifier, int W, int H)
+{
+    ViewParams vp;
+    vp.view = view_d;
+    vp.proj = proj_d;
+    vp.campos = campos_d;
+    vp.tan_fovx = tan_fovx;
+    vp.tan_fovy = tan_fovy;
+    // CF/cuda_rasterizer/rasterizer_impl.cu:222-223
+    vp.focal_y = H / (2.0f * tan_fovy);
+    vp.focal_x = W / (2.0f * tan_fovx);
+    vp.scale_modifier = scale_modifier;
+    vp.W = W;
+    vp.H = H;
+    vp.grid_x = (W + TILE_X - 1) / TILE_X;
+    vp.grid_y = (H + TILE_Y - 1) / TILE_Y;
+    return vp;
+}
+
+struct GeomPtrs {
+    float* depths;
+    float2* means2D;
+    float4* conic_opacity;
+    float* cov3D;
+    float* rgb;
+    uint8_t* clamped;
+    uint32_t* tiles_touched;
+    uint32_t* point_offsets;
+    char* scan_temp;
+    size_t scan_temp_size;
+};
+struct ImgPtrs {
+    float* final_T;
+    uint32_t* n_contrib;
+    uint2* ranges;
+    uint32_t* tile_consumed;  // per tile: list entries the forward blend consumed (counter E of SURVEY.md 8d)
+};
+struct BinPtrs {
+    uint64_t* keys_unsorted;
+    uint64_t* keys;
+    uint32_t* values_unsorted;
+    uint32_t* point_list;
+    char* sort_temp;
+    size_t sort_temp_size;
+};
+
+GeomPtrs geom_from(char* base, int P)
+{
+    size_t off[MI_GEOM_NFIELDS];
+    mi_rast_geometry_layout(P, off);
+    GeomPtrs g;
+    g.depths = (float*)(base + off[MI_GEOM_DEPTHS]);
+    g.means2D = (float2*)(base + off[MI_GEOM_MEANS2D]);
+    g.conic_opacity = (float4*)(base + off[MI_GEOM_CONIC_OPACITY]);
+    g.cov3D = (float*)(base + off[MI_GEOM_COV3D]);
+    g.rgb = (float*)(base + off[MI_GEOM_RGB]);
+    g.clamped = (uint8_t*)(base + off[MI_GEOM_CLAMPED]);
+    g.tiles_touched = (uint32_t*)(base + off[MI_GEOM_TILES_TOUCHED]);
+    g.point_offsets = (uint32_t*)(base + off[MI_GEOM_POINT_OFFSETS]);
+    g.scan_temp = base + off[MI_GEOM_SCAN_TEMP];
+    g.scan_temp_size = scan_temp_bytes(P);
+    return g;
+}
+ImgPtrs img_from(char* base, int W, int H)
+{
+    size_t off[MI_IMG_NFIELDS];
+    mi_rast_image_layout(W, H, off);
+    ImgPtrs m;
+    m.final_T = (float*)(base + off[MI_IMG_FINAL_T]);
+    m.n_contrib = (uint32_t*)(base + off[MI_IMG_N_CONTRIB]);
+    m.ranges = (uint2*)(base + off[MI_IMG_RANGES]);
+    m.tile_consumed = (uint32_t*)(base + off[MI_IMG_TILE_CONSUMED]);
+    return m;
+}
+BinPtrs bin_from(char* base, int R)
+{
+    size_t off[MI_BIN_NFIELDS];
+    mi_rast_binning_layout(R, off);
+    BinPtrs b;
+    b.keys_unsorted = (uint64_t*)(base + off[MI_BIN_KEYS_UNSORTED]);
+    b.keys = (uint64_t*)(base + off[MI_BIN_KEYS]);
+    b.values_unsorted = (uint32_t*)(base + off[MI_BIN_VALUES_UNSORTED]);
+    b.point_list = (uint32_t*)(base + off[MI_BIN_POINT_LIST]);
+    b.sort_temp = base + off[MI_BIN_SORT_TEMP];
+    b.sort_temp_size = sort_temp_bytes(R);
+    return b;
+}
+
+bool channels_supported(int c) { return c == 3 || c == 32 || c == 64; }
+
+// Stages shared by forward and mask_forward: CF/cuda_rasterizer/rasterizer_impl.cu:246-317.
+int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_rast_resize_fn binning_buffer,
+                         void* binning_user, mi_rast_resize_fn image_buffer, void* image_user, int P, int D, int M,
+                         int W, int H, const float* means3D, const float* shs, int colors_given,
+                         const float* opacities, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, const ViewParams& vp, int prefiltered, int* radii, int debug,
+                         hipStream_t stream, GeomPtrs& geom, ImgPtrs& img, BinPtrs& bin, int* num_rendered)
+{
+    size_t goff[MI_GEOM_NFIELDS], ioff[MI_IMG_NFIELDS];
+    const size_t geom_size = mi_rast_geometry_layout(P, goff);
+    char* geom_base = geometry_buffer(geom_size, geometry_user);
+    if (!geom_base) return fail(MI_RAST_ERR_ALLOC, "geometry buffer callback returned NULL");
+    geom = geom_from(geom_base, P);
+    const size_t img_size = mi_rast_image_layout(W, H, ioff);
+    char* img_base = image_buffer(img_size, image_user);
+    if (!img_base) return fail(MI_RAST_ERR_ALLOC, "image buffer callback returned NULL");
+    img = img_from(img_base, W, H);
+
+    // point_offsets[P] doubles as the prefiltered-cull counter slot (scan temp is not live yet)
+    int* cull_counter = (int*)geom.scan_temp;
+    if (prefiltered) HIP_TRY(hipMemsetAsync(cull_counter, 0, sizeof(int), stream));
+    {
+        StageTimer t(stream, MI_STAGE_PREPROCESS);
+        hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
+                           rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
+                           geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
+                           prefiltered, cull_counter);
+    }
+    STAGE_CHECK("preprocess");
+    if (prefiltered) {
+        int culled = 0;
+        HIP_TRY(hipMemcpyAsync(&culled, cull_counter, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (culled)
+            return fail(MI_RAST_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
+    {
+        StageTimer t(stream, MI_STAGE_SCAN);
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(geom.scan_temp, geom.scan_temp_size, geom.tiles_touched,
+                                                 geom.point_offsets, P, stream));
+    }
+    STAGE_CHECK("scan");
+
+    // rasterizer_impl.cu:280-281: the host needs num_rendered to size the binning buffer
+    int R = 0;
+    HIP_TRY(hipMemcpyAsync(&R, geom.point_offsets + P - 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *num_rendered = R;
+
+    size_t boff[MI_BIN_NFIELDS];
+    const size_t bin_size = mi_rast_binning_layout(R, boff);
+    char* bin_base = binning_buffer(bin_size, binning_user);
+    if (!bin_base) return fail(MI_RAST_ERR_ALLOC, "binning buffer callback returned NULL");
+    bin = bin_from(bin_base, R);
+
+    {
+        StageTimer t(stream, MI_STAGE_DUPLICATE);
+        hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.means2D,
+                           geom.depths, geom.point_offsets, bin.keys_unsorted, bin.values_unsorted, radii, vp.grid_x,
+                           vp.grid_y);
+    }
+    STAGE_CHECK("duplicateWithKeys");
+
+    const int bit = (int)mi_rast_get_higher_msb(vp.grid_x * vp.grid_y);
+    if (R > 0) {
+        StageTimer t(stream, MI_STAGE_SORT);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, bin.sort_temp_size, bin.keys_unsorted, bin.keys,
+                                                   bin.values_unsorted, bin.point_list, R, 0, 32 + bit, stream));
+    }
+    STAGE_CHECK("sort");
+    {
+        StageTimer t(stream, MI_STAGE_RANGES);
+        HIP_TRY(hipMemsetAsync(img.ranges, 0, (size_t)vp.grid_x * vp.grid_y * sizeof(uint2), stream));
+        if (R > 0)
+            hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, bin.keys,
+                               img.ranges);
+    }
+    STAGE_CHECK("identifyTileRanges");
+    return MI_RAST_OK;
+}
+
+template <int C, int EXTRA>
+void launch_blend_fwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin,
+                      const GeomPtrs& geom, const float* features, const float* mask, const float* bg,
+                      float* out_color, float* out_mask, float* out_depth)
+{
+    hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+                       bin.point_list, vp.W, vp.H, geom.means2D, features, geom.conic_opacity, mask, geom.depths,
+                       img.final_T, img.n_contrib, img.tile_consumed, bg, out_color, out_mask, out_depth);
+}
+
+template <int C, bool MASKGRAD>
+void launch_blend_bwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin,
+                      const GeomPtrs& geom, const float* colors, const float* bg, const float* dL_dpix,
+                      const float* dL_dout_mask, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                      float* dL_dcolor, float* dL_dmask)
+{
+    hipLaunchKernelGGL((blend_bwd_kernel<C, MASKGRAD>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+                       bin.point_list, vp.W, vp.H, bg, geom.means2D, geom.conic_opacity, colors, img.final_T,
+                       img.n_contrib, dL_dpix, dL_dout_mask, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmask);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mi_rast_last_error(void) { return g_last_error.c_str(); }
+const char* mi_rast_version(void) { return "mi_rast 0.1 (gfx950)"; }
+
+int mi_rast_supported_channels(int* out, int n)
+{
+    const int all[3] = {3, 32, 64};
+    for (int i = 0; i < 3 && i < n; i++) out[i] = all[i];
+    return 3;
+}
+
+// CF/cuda_rasterizer/rasterizer_impl.cu:35-50
+uint32_t mi_rast_get_higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step;
+        else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+size_t mi_rast_geometry_layout(int P, size_t* off)
+{
+    const size_t p = P > 0 ? (size_t)P : 1;
+    Carver c;
+    off[MI_GEOM_DEPTHS] = c.take(p * sizeof(float));
+    off[MI_GEOM_MEANS2D] = c.take(p * sizeof(float2));
+    off[MI_GEOM_CONIC_OPACITY] = c.take(p * sizeof(float4));
+    off[MI_GEOM_COV3D] = c.take(p * 6 * sizeof(float));
+    off[MI_GEOM_RGB] = c.take(p * 3 * sizeof(float));
+    off[MI_GEOM_CLAMPED] = c.take(p * 3);
+    off[MI_GEOM_TILES_TOUCHED] = c.take(p * sizeof(uint32_t));
+    off[MI_GEOM_POINT_OFFSETS] = c.take(p * sizeof(uint32_t));
+    off[MI_GEOM_SCAN_TEMP] = c.take(scan_temp_bytes(P) + 16);
+    return c.off;
+}
+size_t mi_rast_image_layout(int width, int height, size_t* off)
+{
+    const size_t n = (size_t)width * height > 0 ? (size_t)width * height : 1;
+    const size_t tiles = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
+    Carver c;
+    off[MI_IMG_FINAL_T] = c.take(n * sizeof(float));
+    off[MI_IMG_N_CONTRIB] = c.take(n * sizeof(uint32_t));
+    off[MI_IMG_RANGES] = c.take((tiles ? tiles : 1) * sizeof(uint2));
+    off[MI_IMG_TILE_CONSUMED] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
+    return c.off;
+}
+size_t mi_rast_binning_layout(int R, size_t* off)
+{
+    const size_t r = R > 0 ? (size_t)R : 1;
+    Carver c;
+    off[MI_BIN_KEYS_UNSORTED] = c.take(r * sizeof(uint64_t));
+    off[MI_BIN_KEYS] = c.take(r * sizeof(uint64_t));
+    off[MI_BIN_VALUES_UNSORTED] = c.take(r * sizeof(uint32_t));
+    off[MI_BIN_POINT_LIST] = c.take(r * sizeof(uint32_t));
+    off[MI_BIN_SORT_TEMP] = c.take(sort_temp_bytes(R));
+    return c.off;
+}
+
+int mi_rast_profile_enable(int on)
+{
+    if (on && !g_ev_created) {
+        for (int i = 0; i < MI_STAGE_COUNT; i++)
+            for (int k = 0; k < 2; k++)
+                if (hipEventCreate(&g_ev[i][k]) != hipSuccess) return fail(MI_RAST_ERR_HIP, "hipEventCreate failed");
+        g_ev_created = true;
+    }
+    g_profile = on != 0;
+    for (int i = 0; i < MI_STAGE_COUNT; i++) g_ev_used[i] = false;
+    return MI_RAST_OK;
+}
+
+int mi_rast_profile_read(float* ms)
+{
+    for (int i = 0; i < MI_STAGE_COUNT; i++) {
+        ms[i] = 0.f;
+        if (g_ev_created && g_ev_used[i]) {
+            HIP_TRY(hipEventSynchronize(g_ev[i][1]));
+            HIP_TRY(hipEventElapsedTime(&ms[i], g_ev[i][0], g_ev[i][1]));
+        }
+        g_ev_used[i] = false;
+    }
+    return MI_RAST_OK;
+}
+
+int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_rast_resize_fn binning_buffer,
+                    void* binning_user, mi_rast_resize_fn image_buffer, void* image_user, int P, int D, int M,
+                    int channels, const float* background, int width, int height, const float* means3D,
+                    const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                    float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                    const float* mask, float* out_color, float* out_mask, float* out_depth, int* radii, int debug,
+                    void* stream_, int* num_rendered)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (num_rendered) *num_rendered = 0;
+    if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
+    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
+    if (mask && channels != 3) return fail(MI_RAST_ERR_INVALID, "mask/depth variant is built for 3 channels");
+    // CF/cuda_rasterizer/rasterizer_impl.cu:242-245
+    if (channels != 3 && colors_precomp == nullptr)
+        return fail(MI_RAST_ERR_NON_RGB, "For non-RGB, provide precomputed Gaussian colors!");
+    if (!num_rendered || !radii || !out_color) return fail(MI_RAST_ERR_INVALID, "null output pointer");
+
+    const ViewParams vp = make_view(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, scale_modifier, width, height);
+    int rc;
+
+    GeomPtrs geom;
+    ImgPtrs img;
+    BinPtrs bin;
+    rc = geometry_and_binning(geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P,
+                              D, M, width, height, means3D, shs, colors_precomp != nullptr, opacities, scales,
+                              rotations, cov3D_precomp, vp, prefiltered, radii, debug, stream, geom, img, bin,
+                              num_rendered);
+    if (rc) return rc;
+
+    const float* feature_ptr = colors_precomp != nullptr ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:321
+    {
+        StageTimer t(stream, MI_STAGE_BLEND_FWD);
+        if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth);
+        else if (channels == 3) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+        else if (channels == 32) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+        else launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+    }
+    STAGE_CHECK("render");
+    return MI_RAST_OK;
+}
+
+int mi_rast_backward(int P, int D, int M, int channels, int R, const float* background, int width, int height,
+                     const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                     float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                     const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                     float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                     const float* dL_dpix, const float* dL_dout_mask, float* dL_dmean2D, float* dL_dconic,
+                     float* dL_dopacity, float* dL_dcolor, float* dL_dmask, float* dL_dmean3D, float* dL_dcov3D,
+                     float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0) return MI_RAST_OK;
+    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
+    const bool maskgrad = dL_dmask != nullptr;
+    if (maskgrad && (channels != 3 || !dL_dout_mask)) return fail(MI_RAST_ERR_INVALID, "mask gradient needs 3 channels and dL_dout_mask");
+
+    const ViewParams vp = make_view(viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, width, height);
+
+    const GeomPtrs geom = geom_from(geom_buffer, P);
+    const BinPtrs bin = bin_from(binning_buffer, R);
+    const ImgPtrs img = img_from(img_buffer, width, height);
+    const float* color_ptr = (colors_precomp != nullptr) ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:389
+    {
+        StageTimer t(stream, MI_STAGE_BLEND_BWD);
+        if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmask);
+        else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, nullptr);
+        else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, nullptr);
+        else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, nullptr);
+    }
+    STAGE_CHECK("render backward");
+
+    const float* cov3D_ptr = (cov3D_precomp != nullptr) ? cov3D_precomp : geom.cov3D;  // rasterizer_impl.cu:411
+    {
+        StageTimer t(stream, MI_STAGE_GEOM_BWD);
+        hipLaunchKernelGGL(geometry_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, radii, shs,
+                           geom.clamped, scales, rotations, cov3D_ptr, vp, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor,
+                           dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    }
+    STAGE_CHECK("preprocess backward");
+    return MI_RAST_OK;
+}
+
+int mi_rast_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                         uint8_t* present, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0) return MI_RAST_OK;
+    const ViewParams vp = make_view(viewmatrix, projmatrix, nullptr, 1.f, 1.f, 1.f, 16, 16);
+    hipLaunchKernelGGL(check_frustum_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, vp, present);
+    HIP_TRY(hipGetLastError());
+    return MI_RAST_OK;
+}
+
+int mi_rast_mask_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_rast_resize_fn binning_buffer,
+                         void* binning_user, mi_rast_resize_fn image_buffer, void* image_user, int P, int width,
+                         int height, const float* means3D, const float* opacities, const float* mask,
+                         const float* scales, float scale_modifier, const float* rotations,
+                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, float tan_fovx,
+                         float tan_fovy, int prefiltered, float* out_mask, int* radii, int debug, void* stream_,
+                         int* num_rendered)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (num_rendered) *num_rendered = 0;
+    if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
+    if (!num_rendered || !radii || !out_mask || !mask) return fail(MI_RAST_ERR_INVALID, "null pointer");
+    const ViewParams vp = make_view(viewmatrix, projmatrix, nullptr, tan_fovx, tan_fovy, scale_modifier, width, height);
+    int rc;
+    GeomPtrs geom;
+    ImgPtrs img;
+    BinPtrs bin;
+    // DEPTH/cuda_rasterizer/rasterizer_impl.cu:495-521: shs = nullptr, colours "given" (dummy pointer)
+    rc = geometry_and_binning(geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P,
+                              0, 0, width, height, means3D, nullptr, 1, opacities, scales, rotations, cov3D_precomp, vp,
+                              prefiltered, radii, debug, stream, geom, img, bin, num_rendered);
+    if (rc) return rc;
+    {
+        StageTimer t(stream, MI_STAGE_BLEND_FWD);
+        launch_blend_fwd<0, 1>(vp, stream, img, bin, geom, nullptr, mask, nullptr, nullptr, out_mask, nullptr);
+    }
+    STAGE_CHECK("render_mask");
+    return MI_RAST_OK;
+}
+
+int mi_rast_mask_backward(int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
+                          char* img_buffer, const float* dL_dout_mask, float* dL_dmask, int debug, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0) return MI_RAST_OK;
+    ViewParams vp;
+    std::memset(&vp, 0, sizeof(vp));
+    vp.W = width;
+    vp.H = height;
+    vp.grid_x = (width + TILE_X - 1) / TILE_X;
+    vp.grid_y = (height + TILE_Y - 1) / TILE_Y;
+    const GeomPtrs geom = geom_from(geom_buffer, P);
+    const BinPtrs bin = bin_from(binning_buffer, R);
+    const ImgPtrs img = img_from(img_buffer, width, height);
+    {
+        StageTimer t(stream, MI_STAGE_BLEND_BWD);
+        launch_blend_bwd<0, true>(vp, stream, img, bin, geom, nullptr, nullptr, nullptr, dL_dout_mask, nullptr, nullptr,
+                                  nullptr, nullptr, dL_dmask);
+    }
+    STAGE_CHECK("render_mask backward");
+    return MI_RAST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,538 @@
+"""Host-side mirror of the reference's Python extension API, on top of the C-ABI (include/mi_rast.h).
+
+This file plays the role of BOTH the reference's torch glue (CF/rasterize_points.cu:35-216: tensor
+allocation, shape check, P==0 short circuit, M = sh.size(1)) and its Python package
+(CF/diff_gaussian_rasterization_contrastive_f/__init__.py: GaussianRasterizationSettings,
+GaussianRasterizer, _RasterizeGaussians), parameterised by channel count and variant so that ONE
+implementation serves the three reference packages:
+
+    diff_gaussian_rasterization               C = 3                  (BASE/)
+    diff_gaussian_rasterization_contrastive_f C = 32 (or 64)         (CF/)
+    diff_gaussian_rasterization_depth         C = 3 + mask + depth   (DEPTH/)
+
+Same names, argument order, return order and error messages as the reference.  PyTorch is used for
+device memory, streams and autograd plumbing only; all compute is in libmi_rast.so.  There is no
+CPU fallback: missing library or non-GPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    # field order == CF/diff_gaussian_rasterization_contrastive_f/__init__.py:156-168
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# --------------------------------------------------------------------------------------------------
+# C-ABI call helpers (the "_C" layer)
+# --------------------------------------------------------------------------------------------------
+
+def _dev_ptr(t, name, device=None, dtype=torch.float32):
+    """Empty tensor -> NULL (reference convention, CF/.../__init__.py:196-206 + `!= nullptr` branches)."""
+    if t is None or t.numel() == 0:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (got {t.device}); the MI355X rasterizer has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype} (got {t.dtype})")
+    if device is not None and t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    return t.data_ptr()
+
+
+def _contig(t):
+    return t if (t is None or t.numel() == 0) else t.contiguous()
+
+
+class _Resizer:
+    """Replacement for resizeFunctional (CF/rasterize_points.cu:27-33): a growable torch uint8 buffer
+    handed to the library as a C callback."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _lib.RESIZE_FN(self._resize)
+
+    def _resize(self, nbytes, _user):
+        try:
+            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return self.tensor.data_ptr()
+        except Exception:  # allocation failure -> NULL -> MI_RAST_ERR_ALLOC
+            return None
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(_lib.last_error())
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, colors, opacity, mask, scales,
+                               rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                               image_height, image_width, sh, degree, campos, prefiltered, debug):
+    """RasterizeGaussiansCUDA (CF/rasterize_points.cu:35-115; DEPTH/rasterize_points.cu:35-130)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    L = _lib.load()
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    dev = means3D.device
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor; the MI355X rasterizer has no CPU path")
+    radii = torch.zeros(P, dtype=torch.int32, device=dev) if P == 0 else torch.empty(P, dtype=torch.int32, device=dev)
+    geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
+    rendered = 0
+    if P != 0:
+        # the kernels write every element, so no zero-fill pass (reference: torch::full(0.0), :68)
+        out_color = torch.empty((channels, H, W), dtype=torch.float32, device=dev)
+        out_mask = torch.empty((1, H, W), dtype=torch.float32, device=dev) if with_mask_depth else None
+        out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev) if with_mask_depth else None
+        M = sh.size(1) if sh.numel() != 0 else 0
+        t = [_contig(x) for x in (background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp,
+                                   viewmatrix, projmatrix, campos, mask)]
+        bg_c, m3_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, vm_c, pm_c, cp_c, mk_c = t
+        n = C.c_int(0)
+        with torch.cuda.device(dev):
+            rc = L.mi_rast_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), int(channels),
+                _dev_ptr(bg_c, "bg", dev), W, H, _dev_ptr(m3_c, "means3D", dev), _dev_ptr(sh_c, "sh", dev),
+                _dev_ptr(col_c, "colors_precomp", dev), _dev_ptr(op_c, "opacities", dev),
+                _dev_ptr(sc_c, "scales", dev), float(scale_modifier), _dev_ptr(rot_c, "rotations", dev),
+                _dev_ptr(cov_c, "cov3D_precomp", dev), _dev_ptr(vm_c, "viewmatrix", dev),
+                _dev_ptr(pm_c, "projmatrix", dev), _dev_ptr(cp_c, "campos", dev), float(tan_fovx), float(tan_fovy),
+                int(bool(prefiltered)), _dev_ptr(mk_c, "mask", dev) if with_mask_depth else None,
+                out_color.data_ptr(), out_mask.data_ptr() if with_mask_depth else None,
+                out_depth.data_ptr() if with_mask_depth else None, radii.data_ptr(), int(bool(debug)),
+                _stream_ptr(dev), C.byref(n))
+        _check(rc)
+        rendered = n.value
+    else:
+        out_color = torch.zeros((channels, H, W), dtype=torch.float32, device=dev)
+        out_mask = torch.zeros((1, H, W), dtype=torch.float32, device=dev) if with_mask_depth else None
+        out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=dev) if with_mask_depth else None
+    if with_mask_depth:
+        return rendered, out_color, out_mask, out_depth, radii, geom.tensor, binning.tensor, img.tensor
+    return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward_native(channels, with_mask_depth, background, means3D, radii, colors, scales,
+                                        rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
+                                        tan_fovy, dL_dout_color, dL_dout_mask, sh, degree, campos, geomBuffer, R,
+                                        binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (CF/rasterize_points.cu:117-196; DEPTH/rasterize_points.cu)."""
+    L = _lib.load()
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    dev = means3D.device
+    o = dict(device=dev, dtype=torch.float32)
+    dL_dmeans3D = torch.zeros((P, 3), **o)
+    dL_dmeans2D = torch.zeros((P, 3), **o)
+    dL_dcolors = torch.zeros((P, channels), **o)
+    dL_dconic = torch.zeros((P, 2, 2), **o)
+    dL_dopacity = torch.zeros((P, 1), **o)
+    dL_dcov3D = torch.zeros((P, 6), **o)
+    dL_dsh = torch.zeros((P, M, 3), **o)
+    dL_dscales = torch.zeros((P, 3), **o)
+    dL_drotations = torch.zeros((P, 4), **o)
+    dL_dmask = torch.zeros((P,), **o) if with_mask_depth else None
+    if P != 0:
+        t = [_contig(x) for x in (background, means3D, sh, colors, scales, rotations, cov3D_precomp, viewmatrix,
+                                   projmatrix, campos, dL_dout_color, dL_dout_mask, radii)]
+        bg_c, m3_c, sh_c, col_c, sc_c, rot_c, cov_c, vm_c, pm_c, cp_c, dpix_c, dmask_c, radii_c = t
+        with torch.cuda.device(dev):
+            rc = L.mi_rast_backward(
+                P, int(degree), int(M), int(channels), int(R), _dev_ptr(bg_c, "bg", dev), W, H,
+                _dev_ptr(m3_c, "means3D", dev), _dev_ptr(sh_c, "sh", dev), _dev_ptr(col_c, "colors_precomp", dev),
+                _dev_ptr(sc_c, "scales", dev), float(scale_modifier), _dev_ptr(rot_c, "rotations", dev),
+                _dev_ptr(cov_c, "cov3D_precomp", dev), _dev_ptr(vm_c, "viewmatrix", dev),
+                _dev_ptr(pm_c, "projmatrix", dev), _dev_ptr(cp_c, "campos", dev), float(tan_fovx), float(tan_fovy),
+                _dev_ptr(radii_c, "radii", dev, torch.int32), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                imageBuffer.data_ptr(), _dev_ptr(dpix_c, "dL_dout_color", dev),
+                _dev_ptr(dmask_c, "dL_dout_mask", dev) if with_mask_depth else None,
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmask.data_ptr() if with_mask_depth else None, dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                dL_dsh.data_ptr() if M > 0 else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(),
+                int(bool(debug)), _stream_ptr(dev))
+        _check(rc)
+    if with_mask_depth:
+        return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmask, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+                dL_drotations)
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible_native(means3D, viewmatrix, projmatrix):
+    """markVisible (CF/rasterize_points.cu:198-216)."""
+    L = _lib.load()
+    P = means3D.size(0)
+    dev = means3D.device
+    present = torch.zeros(P, dtype=torch.bool, device=dev)
+    if P != 0:
+        m3_c, vm_c, pm_c = _contig(means3D), _contig(viewmatrix), _contig(projmatrix)
+        with torch.cuda.device(dev):
+            rc = L.mi_rast_mark_visible(P, _dev_ptr(m3_c, "means3D", dev), _dev_ptr(vm_c, "viewmatrix", dev),
+                                        _dev_ptr(pm_c, "projmatrix", dev), present.data_ptr(), _stream_ptr(dev))
+        _check(rc)
+    return present
+
+
+def rasterize_mask_gaussians_native(means3D, opacity, mask, scales, rotations, scale_modifier, cov3D_precomp,
+                                    viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width,
+                                    prefiltered, debug):
+    """RasterizeMaskGaussiansCUDA (DEPTH/rasterize_points.cu, mask-only forward)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    L = _lib.load()
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    dev = means3D.device
+    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
+    rendered = 0
+    if P != 0:
+        out_mask = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        t = [_contig(x) for x in (means3D, opacity, mask, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)]
+        m3_c, op_c, mk_c, sc_c, rot_c, cov_c, vm_c, pm_c = t
+        n = C.c_int(0)
+        with torch.cuda.device(dev):
+            rc = L.mi_rast_mask_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, W, H, _dev_ptr(m3_c, "means3D", dev),
+                _dev_ptr(op_c, "opacities", dev), _dev_ptr(mk_c, "mask", dev), _dev_ptr(sc_c, "scales", dev),
+                float(scale_modifier), _dev_ptr(rot_c, "rotations", dev), _dev_ptr(cov_c, "cov3D_precomp", dev),
+                _dev_ptr(vm_c, "viewmatrix", dev), _dev_ptr(pm_c, "projmatrix", dev), float(tan_fovx),
+                float(tan_fovy), int(bool(prefiltered)), out_mask.data_ptr(), radii.data_ptr(), int(bool(debug)),
+                _stream_ptr(dev), C.byref(n))
+        _check(rc)
+        rendered = n.value
+    else:
+        out_mask = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+    return rendered, out_mask, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_mask_gaussians_backward_native(means3D, dL_dout_mask, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    L = _lib.load()
+    P = means3D.size(0)
+    H, W = dL_dout_mask.size(-2), dL_dout_mask.size(-1)
+    dev = means3D.device
+    dL_dmask = torch.zeros((P,), dtype=torch.float32, device=dev)
+    if P != 0:
+        d_c = _contig(dL_dout_mask)
+        with torch.cuda.device(dev):
+            rc = L.mi_rast_mask_backward(P, int(R), W, H, geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                                         imageBuffer.data_ptr(), _dev_ptr(d_c, "dL_dout_mask", dev),
+                                         dL_dmask.data_ptr(), int(bool(debug)), _stream_ptr(dev))
+        _check(rc)
+    return dL_dmask
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd + nn.Module layer, generated per (channels, variant)
+# --------------------------------------------------------------------------------------------------
+
+_MSG_COLORS = 'Please provide excatly one of either SHs or precomputed colors!'
+_MSG_COV = 'Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!'
+
+
+def _make_plain(channels):
+    """BASE / CF packages: CF/diff_gaussian_rasterization_contrastive_f/__init__.py:21-220."""
+
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                    raster_settings):
+            rs = raster_settings
+            args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                    rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+
+            def call():
+                (bg, m3, col, op, sc, rot, smod, cov, vm, pm, tx, ty, ih, iw, sh_, deg, cp, pre, dbg) = args
+                return rasterize_gaussians_native(channels, False, bg, m3, col, op, None, sc, rot, smod, cov, vm, pm,
+                                                  tx, ty, ih, iw, sh_, deg, cp, pre, dbg)
+
+            if rs.debug:
+                cpu_args = cpu_deep_copy_tuple(args)  # Copy them before they can be corrupted
+                try:
+                    num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = call()
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = call()
+            ctx.raster_settings = rs
+            ctx.num_rendered = num_rendered
+            ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                                  binningBuffer, imgBuffer)
+            ctx.mark_non_differentiable(radii)
+            return color, radii
+
+        @staticmethod
+        def backward(ctx, grad_out_color, _):
+            num_rendered = ctx.num_rendered
+            rs = ctx.raster_settings
+            (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+             imgBuffer) = ctx.saved_tensors
+            args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
+                    geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug)
+
+            def call():
+                (bg, m3, rad, col, sc, rot, smod, cov, vm, pm, tx, ty, gout, sh_, deg, cp, gb, nr, bb, ib, dbg) = args
+                return rasterize_gaussians_backward_native(channels, False, bg, m3, rad, col, sc, rot, smod, cov, vm,
+                                                           pm, tx, ty, gout, None, sh_, deg, cp, gb, nr, bb, ib, dbg)
+
+            if rs.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    res = call()
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise ex
+            else:
+                res = call()
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = res
+            return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
+                    grad_rotations, grad_cov3Ds_precomp, None)
+
+    def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                            raster_settings):
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            with torch.no_grad():
+                rs = self.raster_settings
+                visible = mark_visible_native(positions, rs.viewmatrix, rs.projmatrix)
+            return visible
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None):
+            raster_settings = self.raster_settings
+            if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+                raise Exception(_MSG_COLORS)
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                    ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception(_MSG_COV)
+            if shs is None:
+                shs = torch.Tensor([])
+            if colors_precomp is None:
+                colors_precomp = torch.Tensor([])
+            if scales is None:
+                scales = torch.Tensor([])
+            if rotations is None:
+                rotations = torch.Tensor([])
+            if cov3D_precomp is None:
+                cov3D_precomp = torch.Tensor([])
+            return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                       cov3D_precomp, raster_settings)
+
+    return _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer
+
+
+def _make_depth():
+    """DEPTH package: DEPTH/diff_gaussian_rasterization_depth/__init__.py:21-391."""
+    channels = 3
+
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, mask, scales, rotations, cov3Ds_precomp,
+                    raster_settings):
+            rs = raster_settings
+            args = (rs.bg, means3D, colors_precomp, opacities, mask, scales, rotations, rs.scale_modifier,
+                    cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                    rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+
+            def call():
+                (bg, m3, col, op, mk, sc, rot, smod, cov, vm, pm, tx, ty, ih, iw, sh_, deg, cp, pre, dbg) = args
+                return rasterize_gaussians_native(channels, True, bg, m3, col, op, mk, sc, rot, smod, cov, vm, pm, tx,
+                                                  ty, ih, iw, sh_, deg, cp, pre, dbg)
+
+            if rs.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    res = call()
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                res = call()
+            num_rendered, color, out_mask, depth, radii, geomBuffer, binningBuffer, imgBuffer = res
+            ctx.raster_settings = rs
+            ctx.num_rendered = num_rendered
+            ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                                  binningBuffer, imgBuffer)
+            ctx.mark_non_differentiable(radii)
+            return color, out_mask, depth, radii
+
+        @staticmethod
+        def backward(ctx, grad_out_color, grad_out_mask, grad_out_depth, _):
+            num_rendered = ctx.num_rendered
+            rs = ctx.raster_settings
+            (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+             imgBuffer) = ctx.saved_tensors
+            args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_mask, sh,
+                    rs.sh_degree, rs.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug)
+
+            def call():
+                (bg, m3, rad, col, sc, rot, smod, cov, vm, pm, tx, ty, gout, gmask, sh_, deg, cp, gb, nr, bb, ib,
+                 dbg) = args
+                return rasterize_gaussians_backward_native(channels, True, bg, m3, rad, col, sc, rot, smod, cov, vm,
+                                                           pm, tx, ty, gout, gmask, sh_, deg, cp, gb, nr, bb, ib, dbg)
+
+            if rs.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    res = call()
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise ex
+            else:
+                res = call()
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_mask, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = res
+            return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_mask, grad_scales,
+                    grad_rotations, grad_cov3Ds_precomp, None)
+
+    class _RasterizeMaskGaussians(torch.autograd.Function):
+        # DEPTH/diff_gaussian_rasterization_depth/__init__.py:185-292
+        @staticmethod
+        def forward(ctx, means3D, means2D, opacities, mask, scales, rotations, cov3Ds_precomp, raster_settings):
+            rs = raster_settings
+            num_rendered, out_mask, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_mask_gaussians_native(
+                means3D, opacities, mask, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.prefiltered, rs.debug)
+            ctx.raster_settings = rs
+            ctx.num_rendered = num_rendered
+            ctx.save_for_backward(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, radii, geomBuffer,
+                                  binningBuffer, imgBuffer)
+            ctx.mark_non_differentiable(radii)
+            return out_mask, radii
+
+        @staticmethod
+        def backward(ctx, grad_out_mask, _):
+            rs = ctx.raster_settings
+            (means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, radii, geomBuffer, binningBuffer,
+             imgBuffer) = ctx.saved_tensors
+            grad_mask = rasterize_mask_gaussians_backward_native(means3D, grad_out_mask, geomBuffer, ctx.num_rendered,
+                                                                 binningBuffer, imgBuffer, rs.debug)
+            # only the mask receives a real gradient; the reference hands ZEROS (not None) to every other input
+            # (DEPTH/.../__init__.py:278-290) -- kept, but shaped like the inputs so autograd accepts them.
+            z = [torch.zeros_like(t) if need else None for t, need in
+                 zip((means3D, means2D, opacities), ctx.needs_input_grad[0:3])]
+            z2 = [torch.zeros_like(t) if (need and t.numel()) else None for t, need in
+                  zip((scales, rotations, cov3Ds_precomp), ctx.needs_input_grad[4:7])]
+            return z[0], z[1], z[2], grad_mask, z2[0], z2[1], z2[2], None
+
+    def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, mask, scales, rotations, cov3Ds_precomp,
+                            raster_settings):
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, mask, scales, rotations,
+                                         cov3Ds_precomp, raster_settings)
+
+    def rasterize_mask_gaussians(means3D, means2D, opacities, mask, scales, rotations, cov3Ds_precomp,
+                                 raster_settings):
+        return _RasterizeMaskGaussians.apply(means3D, means2D, opacities, mask, scales, rotations, cov3Ds_precomp,
+                                             raster_settings)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            with torch.no_grad():
+                rs = self.raster_settings
+                visible = mark_visible_native(positions, rs.viewmatrix, rs.projmatrix)
+            return visible
+
+        def forward(self, means3D, means2D, opacities, mask, shs=None, colors_precomp=None, scales=None,
+                    rotations=None, cov3D_precomp=None):
+            raster_settings = self.raster_settings
+            if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+                raise Exception(_MSG_COLORS)
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                    ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception(_MSG_COV)
+            if shs is None:
+                shs = torch.Tensor([])
+            if colors_precomp is None:
+                colors_precomp = torch.Tensor([])
+            if scales is None:
+                scales = torch.Tensor([])
+            if rotations is None:
+                rotations = torch.Tensor([])
+            if cov3D_precomp is None:
+                cov3D_precomp = torch.Tensor([])
+            return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, mask, scales, rotations,
+                                       cov3D_precomp, raster_settings)
+
+        def forward_mask(self, means3D, means2D, opacities, mask, scales=None, rotations=None, cov3D_precomp=None):
+            raster_settings = self.raster_settings
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                    ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception(_MSG_COV)
+            if scales is None:
+                scales = torch.Tensor([])
+            if rotations is None:
+                rotations = torch.Tensor([])
+            if cov3D_precomp is None:
+                cov3D_precomp = torch.Tensor([])
+            return rasterize_mask_gaussians(means3D, means2D, opacities, mask, scales, rotations, cov3D_precomp,
+                                            raster_settings)
+
+    return _RasterizeGaussians, _RasterizeMaskGaussians, rasterize_gaussians, rasterize_mask_gaussians, \
+        GaussianRasterizer
+
+
+_PLAIN_CACHE = {}
+
+
+def make_rasterizer(channels: int):
+    """(autograd Function, functional wrapper, nn.Module) for the plain C-channel rasterizer."""
+    if channels not in _PLAIN_CACHE:
+        _PLAIN_CACHE[channels] = _make_plain(channels)
+    return _PLAIN_CACHE[channels]
+
+
+_DEPTH = None
+
+
+def make_depth_rasterizer():
+    global _DEPTH
+    if _DEPTH is None:
+        _DEPTH = _make_depth()
+    return _DEPTH

@@ -1,0 +1,240 @@
+"""Shared helpers for the parity tests: build one set of seeded inputs, run it through the CPU oracle
+and through the HIP C-ABI path, and compare.
+
+Tolerances (BASELINE.md section 3 / north_star): bit-exact on the integer tile/sort path; <= 1e-4
+relative (with an absolute floor scaled to the tensor's max-abs) on the float image and gradients.
+alpha >= 1/255 and T < 1e-4 are DISCONTINUITIES of the reference function itself: a 1-ulp difference
+in exp() (libm vs v_exp_f32 -- CUDA's own expf differs from both) can flip a pixel-Gaussian pair in
+or out.  Such flips are allowed for a tiny fraction of elements (FLIP_FRAC) and reported.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from oracle import saga_oracle as so
+from seganygaussians_amd import scenes
+
+RTOL = 1e-4
+FLIP_FRAC = 2e-5      # fraction of elements allowed outside tolerance because of threshold flips
+
+
+def make_inputs(P, W, H, C, seed=0, *, focal=None, log_scale=None, log_scale_std=0.6, with_shs=False, sh_degree=0,
+                use_cov=False, use_mask=False, bg=None, scale_modifier=1.0, camera="front", z_range=(1.5, 12.0)):
+    focal = focal or 0.85 * W
+    log_scale = math.log(0.05) if log_scale is None else log_scale
+    sc = scenes.make_scene(P, W, H, focal, C, log_scale, log_scale_std, seed=seed, with_shs=with_shs, z_range=z_range)
+    cam = scenes.look_at_camera(W, H, focal) if camera == "front" else scenes.orbit_camera(W, H, focal, 0.2, 0.07)
+    rng = np.random.default_rng(seed + 1000)
+    if bg is None:
+        bg = np.zeros(C, np.float32)
+    elif isinstance(bg, str) and bg == "random":
+        bg = rng.uniform(0, 1, C).astype(np.float32)
+    cov = None
+    if use_cov:
+        # world covariance in fp64 from scale/rotation, handed over as cov3D_precomp
+        q = sc.rotations.astype(np.float64)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                      2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                      2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+        S = sc.scales.astype(np.float64)[:, None, :] * scale_modifier
+        L = R * S
+        Sig = L @ L.transpose(0, 2, 1)
+        cov = np.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]],
+                       1).astype(np.float32)
+    mask = rng.uniform(0, 1, P).astype(np.float32) if use_mask else None
+    return so.Inputs(means3D=sc.means3D, opacities=sc.opacities, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
+                     campos=cam.campos, bg=bg, image_width=W, image_height=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                     channels=C, scale_modifier=scale_modifier, sh_degree=sh_degree,
+                     shs=sc.shs if with_shs else None, colors_precomp=None if with_shs else sc.features,
+                     scales=None if use_cov else sc.scales, rotations=None if use_cov else sc.rotations,
+                     cov3D_precomp=cov, mask=mask)
+
+
+def inputs_from_config(name, P=None, seed=0, with_shs=False, use_mask=False):
+    c = scenes.CONFIGS[name]
+    inp = make_inputs(c["P"] if P is None else P, c["W"], c["H"], c["C"], seed, focal=c["focal"],
+                      log_scale=c["ls_mean"], log_scale_std=c["ls_std"], with_shs=with_shs,
+                      sh_degree=3 if with_shs else 0, use_mask=use_mask)
+    return inp
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU (C-ABI) runner
+# ---------------------------------------------------------------------------------------------------
+
+class GpuRun:
+    """Runs the HIP path through seganygaussians_amd.rasterizer's native entry points (the same functions
+    the drop-in packages call) and keeps everything needed for comparisons."""
+
+    def __init__(self, inp: so.Inputs, device="cuda:0"):
+        import torch
+        from seganygaussians_amd import rasterizer as R
+        self.torch, self.R, self.inp, self.dev = torch, R, inp, torch.device(device)
+        t = lambda a, shape=None: (torch.empty(0) if a is None else
+                                   torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(self.dev))
+        P = np.asarray(inp.means3D).reshape(-1, 3).shape[0]
+        self.P = P
+        self.means3D = t(np.asarray(inp.means3D).reshape(-1, 3))
+        self.opac = t(np.asarray(inp.opacities).reshape(-1, 1))
+        self.shs = t(None if inp.shs is None else np.asarray(inp.shs).reshape(P, -1, 3))
+        self.colors = t(inp.colors_precomp)
+        self.scales, self.rots, self.cov = t(inp.scales), t(inp.rotations), t(inp.cov3D_precomp)
+        self.view, self.proj, self.campos, self.bg = t(inp.viewmatrix), t(inp.projmatrix), t(inp.campos), t(inp.bg)
+        self.mask = t(inp.mask)
+        self.with_mask = inp.mask is not None
+
+    def forward(self, debug=False):
+        i = self.inp
+        res = self.R.rasterize_gaussians_native(
+            i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
+            self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,
+            i.image_width, self.shs, i.sh_degree, self.campos, i.prefiltered, debug)
+        if self.with_mask:
+            (self.num_rendered, self.color, self.out_mask, self.out_depth, self.radii, self.geom, self.binning,
+             self.img) = res
+        else:
+            self.num_rendered, self.color, self.radii, self.geom, self.binning, self.img = res
+            self.out_mask = self.out_depth = None
+        return self
+
+    def backward(self, dL_dout_color, dL_dout_mask=None, debug=False):
+        i, torch = self.inp, self.torch
+        g = torch.as_tensor(np.ascontiguousarray(dL_dout_color, np.float32)).to(self.dev)
+        gm = None
+        if self.with_mask:
+            gm = torch.as_tensor(np.ascontiguousarray(
+                np.zeros((1, i.image_height, i.image_width), np.float32) if dL_dout_mask is None else dL_dout_mask,
+                np.float32)).to(self.dev)
+        res = self.R.rasterize_gaussians_backward_native(
+            i.channels, self.with_mask, self.bg, self.means3D, self.radii, self.colors, self.scales, self.rots,
+            i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, g, gm, self.shs, i.sh_degree,
+            self.campos, self.geom, self.num_rendered, self.binning, self.img, debug)
+        names = (["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmask", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
+                  "dL_dscales", "dL_drotations"] if self.with_mask else
+                 ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+                  "dL_drotations"])
+        self.grads = {k: v.detach().cpu().numpy() for k, v in zip(names, res)}
+        return self.grads
+
+    # ---- views into the opaque buffers (private layout published by mi_rast_*_layout) ----
+    def _view(self, buf, off, count, dtype):
+        raw = buf.detach().cpu().numpy()
+        nbytes = count * np.dtype(dtype).itemsize
+        return raw[off:off + nbytes].view(dtype).copy()
+
+    def geom_fields(self):
+        from seganygaussians_amd import _lib
+        _, off = _lib.geometry_layout(self.P)
+        P = self.P
+        return dict(depths=self._view(self.geom, off["depths"], P, np.float32),
+                    means2D=self._view(self.geom, off["means2D"], 2 * P, np.float32),
+                    conic_opacity=self._view(self.geom, off["conic_opacity"], 4 * P, np.float32),
+                    cov3D=self._view(self.geom, off["cov3D"], 6 * P, np.float32),
+                    rgb=self._view(self.geom, off["rgb"], 3 * P, np.float32),
+                    clamped=self._view(self.geom, off["clamped"], 3 * P, np.uint8),
+                    tiles_touched=self._view(self.geom, off["tiles_touched"], P, np.uint32),
+                    point_offsets=self._view(self.geom, off["point_offsets"], P, np.uint32))
+
+    def bin_fields(self):
+        from seganygaussians_amd import _lib
+        R = self.num_rendered
+        _, off = _lib.binning_layout(R)
+        return dict(keys_unsorted=self._view(self.binning, off["keys_unsorted"], R, np.uint64),
+                    keys=self._view(self.binning, off["keys"], R, np.uint64),
+                    values_unsorted=self._view(self.binning, off["values_unsorted"], R, np.uint32),
+                    point_list=self._view(self.binning, off["point_list"], R, np.uint32))
+
+    def img_fields(self):
+        from seganygaussians_amd import _lib
+        i = self.inp
+        W, H = i.image_width, i.image_height
+        _, off = _lib.image_layout(W, H)
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        return dict(final_T=self._view(self.img, off["final_T"], W * H, np.float32),
+                    n_contrib=self._view(self.img, off["n_contrib"], W * H, np.uint32),
+                    ranges=self._view(self.img, off["ranges"], 2 * tiles, np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# comparisons
+# ---------------------------------------------------------------------------------------------------
+
+def close_report(got, want, rtol=RTOL, floor=None):
+    """|got-want| <= rtol*|want| + rtol*max|want| ; returns (fraction outside, max err, scale)."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if want.size == 0:
+        return 0.0, 0.0, 0.0
+    scale = float(np.abs(want).max())
+    tol = rtol * np.abs(want) + rtol * max(scale, 1e-30) if floor is None else rtol * np.abs(want) + floor
+    err = np.abs(got - want)
+    bad = ~(err <= tol)
+    return float(bad.mean()), float(err.max()), scale
+
+
+def assert_close(name, got, want, rtol=RTOL, flip_frac=0.0):
+    frac, emax, scale = close_report(got, want, rtol)
+    assert frac <= flip_frac, f"{name}: fraction outside tol {frac:.3e} (allowed {flip_frac:.1e}); max err {emax:.3e}, scale {scale:.3e}"
+    return frac
+
+
+def compare_integer_path(gpu: GpuRun, fwd: so.ForwardOut):
+    """Bit-exact: radii, tiles_touched, point_offsets, num_rendered, unsorted + sorted (key,value) lists, ranges."""
+    st = fwd.state
+    np.testing.assert_array_equal(gpu.radii.cpu().numpy(), fwd.radii, err_msg="radii")
+    assert gpu.num_rendered == fwd.num_rendered, (gpu.num_rendered, fwd.num_rendered)
+    g = gpu.geom_fields()
+    np.testing.assert_array_equal(g["tiles_touched"], st.field(so.F_TILES_TOUCHED), err_msg="tiles_touched")
+    np.testing.assert_array_equal(g["point_offsets"], st.field(so.F_POINT_OFFSETS), err_msg="point_offsets")
+    vis = fwd.radii > 0
+    # depths / means2D feed the integer path (key bits, rects): bit-exact where the Gaussian is visible
+    np.testing.assert_array_equal(g["depths"].view(np.uint32)[vis], st.field(so.F_DEPTHS).view(np.uint32)[vis],
+                                  err_msg="depth bits")
+    np.testing.assert_array_equal(g["means2D"].view(np.uint32).reshape(-1, 2)[vis],
+                                  st.field(so.F_MEANS2D).view(np.uint32).reshape(-1, 2)[vis], err_msg="means2D bits")
+    b = gpu.bin_fields()
+    np.testing.assert_array_equal(b["keys_unsorted"], st.field(so.F_KEYS_UNSORTED), err_msg="keys_unsorted")
+    np.testing.assert_array_equal(b["values_unsorted"], st.field(so.F_VALUES_UNSORTED), err_msg="values_unsorted")
+    np.testing.assert_array_equal(b["keys"], st.field(so.F_KEYS_SORTED), err_msg="sorted keys")
+    np.testing.assert_array_equal(b["point_list"], st.field(so.F_POINT_LIST), err_msg="point_list")
+    im = gpu.img_fields()
+    np.testing.assert_array_equal(im["ranges"], st.field(so.F_RANGES), err_msg="tile ranges")
+
+
+def compare_float_forward(gpu: GpuRun, fwd: so.ForwardOut, flip_frac=FLIP_FRAC):
+    rep = {}
+    rep["color"] = assert_close("out_color", gpu.color.cpu().numpy(), fwd.color, flip_frac=flip_frac)
+    im = gpu.img_fields()
+    rep["final_T"] = assert_close("final_T", im["final_T"], fwd.state.field(so.F_FINAL_T), flip_frac=flip_frac)
+    nc_g, nc_o = im["n_contrib"], fwd.state.field(so.F_N_CONTRIB)
+    rep["n_contrib_mismatch"] = float((nc_g != nc_o).mean())
+    assert rep["n_contrib_mismatch"] <= max(flip_frac, 1e-4), rep
+    if gpu.with_mask:
+        rep["mask"] = assert_close("out_mask", gpu.out_mask.cpu().numpy(), fwd.mask, flip_frac=flip_frac)
+        rep["depth"] = assert_close("out_depth", gpu.out_depth.cpu().numpy(), fwd.depth, flip_frac=flip_frac)
+    # conic/opacity, cov3D: float path of preprocess (should in fact be bit-identical: same op order)
+    g = gpu.geom_fields()
+    vis = fwd.radii > 0
+    co_g = g["conic_opacity"].reshape(-1, 4)[vis]
+    co_o = fwd.state.field(so.F_CONIC_OPACITY).reshape(-1, 4)[vis]
+    rep["conic_bits_equal"] = bool(np.array_equal(co_g.view(np.uint32), co_o.view(np.uint32)))
+    assert_close("conic_opacity", co_g, co_o)
+    return rep
+
+
+GRAD_FLIP_FRAC = 2e-4
+
+
+def compare_gradients(grads: dict, bwd: so.BackwardOut, rtol=RTOL, flip_frac=GRAD_FLIP_FRAC, skip=()):
+    rep = {}
+    for k, got in grads.items():
+        want = getattr(bwd, k)
+        if want is None or k in skip:
+            continue
+        want = np.asarray(want).reshape(got.shape)
+        rep[k] = assert_close(k, got, want, rtol=rtol, flip_frac=flip_frac)
+    return rep

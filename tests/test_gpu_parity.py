@@ -1,0 +1,200 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact on the integer tile/sort path; <= 1e-4 relative on the float image
+and on every gradient.  Run on a real MI355X:  python -m pytest tests -m gpu -x -q
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import saga_oracle as so
+from seganygaussians_amd import scenes
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+def _fwd_bwd(inp, grad_seed=1, check_int=True, use_mask_grad=False, skip=()):
+    gpu = hp.GpuRun(inp).forward()
+    fwd = so.forward(inp)
+    assert fwd.rc == 0
+    if check_int:
+        hp.compare_integer_path(gpu, fwd)
+    rep = hp.compare_float_forward(gpu, fwd)
+    W, H, C = inp.image_width, inp.image_height, inp.channels
+    dL = scenes.make_grad_image(C, H, W, seed=grad_seed)
+    dLm = None
+    if inp.mask is not None:
+        dLm = (np.random.default_rng(grad_seed + 7).normal(0, 1, (1, H, W)) / (W * H)).astype(np.float32)
+    grads = gpu.backward(dL, dLm)
+    bwd = so.backward(inp, fwd, dL, None if dLm is None else dLm[0])
+    rep.update(hp.compare_gradients(grads, bwd, skip=skip))
+    return rep, gpu, fwd
+
+
+def test_cfg1_rgb_precomp():
+    """BASELINE config 1: 10k Gaussians, 256x256, RGB (precomputed colours)."""
+    rep, gpu, fwd = _fwd_bwd(hp.inputs_from_config("cfg1"))
+    assert fwd.num_rendered > 40_000
+
+
+def test_cfg1_sh_degree3_random_bg():
+    inp = hp.inputs_from_config("cfg1", with_shs=True)
+    inp.bg = np.array([0.2, 0.7, 0.4], np.float32)
+    _fwd_bwd(inp)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_sh_lower_degrees(deg):
+    inp = hp.make_inputs(3000, 160, 120, 3, seed=20 + deg, with_shs=True, sh_degree=deg, camera="orbit")
+    _fwd_bwd(inp)
+
+
+def test_features32_dense():
+    """Reduced BASELINE config 3: 32-D features, dense overlap (long per-tile lists, early termination)."""
+    inp = hp.make_inputs(60_000, 640, 360, 32, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
+    rep, gpu, fwd = _fwd_bwd(inp)
+    c = fwd.state.counters()
+    assert c["E"] < c["R"], "scene should exercise early termination"
+
+
+def test_features32_odd_size_random_bg():
+    """Image size not a multiple of 16: edge tiles with pixels outside the image (forward.cu:288-290,378)."""
+    inp = hp.make_inputs(8_000, 203, 117, 32, seed=4, bg="random", camera="orbit")
+    _fwd_bwd(inp)
+
+
+def test_features64():
+    """BASELINE config 5 channel count (64-D), reduced size."""
+    inp = hp.make_inputs(20_000, 320, 208, 64, seed=5, log_scale=math.log(0.04))
+    _fwd_bwd(inp)
+
+
+def test_depth_variant_with_mask():
+    """BASELINE config 2 shape (RGB + mask + depth), reduced size, SH colours."""
+    inp = hp.make_inputs(20_000, 480, 272, 3, seed=6, with_shs=True, sh_degree=3, use_mask=True, bg="random")
+    _fwd_bwd(inp)
+
+
+def test_cov3d_precomp():
+    inp = hp.make_inputs(5_000, 256, 192, 3, seed=7, use_cov=True)
+    _fwd_bwd(inp)
+
+
+def test_scale_modifier():
+    inp = hp.make_inputs(5_000, 256, 192, 32, seed=8, scale_modifier=1.6)
+    _fwd_bwd(inp)
+
+
+def test_mask_only_pair():
+    """mask-only render pair (DEPTH forward_mask)."""
+    import torch
+    from seganygaussians_amd import rasterizer as R
+    inp = hp.make_inputs(10_000, 320, 240, 3, seed=9, use_mask=True)
+    g = hp.GpuRun(inp)
+    nr, out_mask, radii, geom, binning, img = R.rasterize_mask_gaussians_native(
+        g.means3D, g.opac, g.mask, g.scales, g.rots, 1.0, g.cov, g.view, g.proj, inp.tanfovx, inp.tanfovy,
+        inp.image_height, inp.image_width, False, False)
+    fwd = so.mask_forward(inp)
+    assert nr == fwd.num_rendered
+    np.testing.assert_array_equal(radii.cpu().numpy(), fwd.radii)
+    hp.assert_close("mask", out_mask.cpu().numpy(), fwd.mask, flip_frac=hp.FLIP_FRAC)
+    dLm = np.random.default_rng(3).normal(0, 1, (1, inp.image_height, inp.image_width)).astype(np.float32)
+    gm = R.rasterize_mask_gaussians_backward_native(g.means3D, torch.as_tensor(dLm).cuda(), geom, nr, binning, img, False)
+    want = so.mask_backward(inp, fwd, dLm[0])
+    hp.assert_close("dL_dmask", gm.cpu().numpy(), want, flip_frac=hp.GRAD_FLIP_FRAC)
+
+
+def test_mark_visible():
+    from seganygaussians_amd import rasterizer as R
+    inp = hp.make_inputs(5000, 64, 64, 3, seed=11, z_range=(-3.0, 5.0))
+    g = hp.GpuRun(inp)
+    got = R.mark_visible_native(g.means3D, g.view, g.proj).cpu().numpy()
+    want = so.mark_visible(inp.means3D, inp.viewmatrix, inp.projmatrix)
+    np.testing.assert_array_equal(got, want)
+    assert 0 < want.sum() < len(want)
+
+
+def test_edge_cases_empty_and_culled():
+    import torch
+    from seganygaussians_amd import rasterizer as R
+    # P == 0: image all zeros (NOT background), num_rendered 0 (rasterize_points.cu:80-114)
+    e = torch.empty(0, device="cuda")
+    bg = torch.tensor([0.3, 0.4, 0.5], device="cuda")
+    eye = torch.eye(4, device="cuda")
+    nr, color, radii, *_ = R.rasterize_gaussians_native(3, False, bg, torch.empty(0, 3, device="cuda"), e, e, None, e, e,
+                                                       1.0, e, eye, eye, 1.0, 1.0, 32, 48, e, 0, torch.zeros(3, device="cuda"),
+                                                       False, False)
+    assert nr == 0 and color.shape == (3, 32, 48) and float(color.abs().max()) == 0.0 and radii.numel() == 0
+    # every Gaussian behind the camera: num_rendered == 0, every pixel == bg (rasterizer_impl.cu:310-317, forward.cu:383)
+    inp = hp.make_inputs(500, 40, 24, 3, seed=12, z_range=(-5.0, -1.0), bg="random")
+    gpu = hp.GpuRun(inp).forward()
+    fwd = so.forward(inp)
+    assert gpu.num_rendered == 0 == fwd.num_rendered
+    np.testing.assert_array_equal(gpu.color.cpu().numpy(), fwd.color)
+    np.testing.assert_array_equal(gpu.color.cpu().numpy(), np.broadcast_to(inp.bg[:, None, None], (3, 24, 40)))
+    grads = gpu.backward(scenes.make_grad_image(3, 24, 40))
+    assert all(float(np.abs(v).max()) == 0.0 for v in grads.values() if v.size)
+    # single Gaussian exactly on a pixel centre
+    inp = hp.make_inputs(1, 32, 32, 3, seed=13)
+    inp.means3D = np.array([[0.0, 0.0, 4.0]], np.float32)
+    _fwd_bwd(inp)
+
+
+def test_non_rgb_without_colors_errors():
+    import torch
+    from seganygaussians_amd import rasterizer as R
+    inp = hp.make_inputs(10, 32, 32, 3, seed=1, with_shs=True, sh_degree=1)
+    g = hp.GpuRun(inp)
+    with pytest.raises(RuntimeError, match="For non-RGB, provide precomputed Gaussian colors!"):
+        R.rasterize_gaussians_native(32, False, torch.zeros(32, device="cuda"), g.means3D, torch.empty(0), g.opac, None,
+                                     g.scales, g.rots, 1.0, g.cov, g.view, g.proj, inp.tanfovx, inp.tanfovy, 32, 32,
+                                     g.shs, 1, g.campos, False, False)
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        R.rasterize_gaussians_native(3, False, g.bg, g.means3D.reshape(-1), g.colors, g.opac, None, g.scales, g.rots, 1.0,
+                                     g.cov, g.view, g.proj, inp.tanfovx, inp.tanfovy, 32, 32, g.shs, 1, g.campos, False,
+                                     False)
+
+
+def test_full_size_cfg3_properties():
+    """BASELINE config 3 at FULL size (1M Gaussians, 1080p, 32-D) through size-independent properties:
+    sortedness + stability of the key list, range consistency, sum(tiles_touched) == R, linearity of the
+    render in the features, and the closed-form identity sum_ch-weighted gradient == <render, dL>."""
+    import torch
+    inp = hp.inputs_from_config("cfg3")
+    gpu = hp.GpuRun(inp).forward()
+    R = gpu.num_rendered
+    g, b, im = gpu.geom_fields(), gpu.bin_fields(), gpu.img_fields()
+    assert int(g["tiles_touched"].astype(np.int64).sum()) == R == int(g["point_offsets"][-1])
+    keys, vals = b["keys"], b["point_list"]
+    assert np.all(keys[1:] >= keys[:-1]), "keys ascending"
+    same = keys[1:] == keys[:-1]
+    assert np.all(vals[1:][same] > vals[:-1][same]), "stable: equal keys keep Gaussian-index order"
+    # sorted multiset == unsorted multiset (checksum of checksums)
+    assert int(np.bitwise_xor.reduce(keys)) == int(np.bitwise_xor.reduce(b["keys_unsorted"]))
+    assert int(vals.astype(np.uint64).sum()) == int(b["values_unsorted"].astype(np.uint64).sum())
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    ranges = im["ranges"].reshape(-1, 2).astype(np.int64)
+    counts = np.bincount(tiles, minlength=len(ranges))
+    np.testing.assert_array_equal(ranges[:, 1] - ranges[:, 0], counts)
+    assert np.all(im["n_contrib"].reshape(-1) <= 200000)
+    # linearity in the features (bg = 0): render(2*f1 - 0.5*f2) == 2*render(f1) - 0.5*render(f2)
+    c1 = gpu.color.clone()
+    f1 = gpu.colors
+    f2 = torch.roll(f1, 1, dims=1).contiguous()
+    gpu.colors = f2
+    c2 = gpu.forward().color.clone()
+    gpu.colors = (2.0 * f1 - 0.5 * f2).contiguous()
+    c3 = gpu.forward().color
+    ref = 2.0 * c1 - 0.5 * c2
+    err = float((c3 - ref).abs().max())
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), err
+    # Euler identity: render is linear in features => sum(f * dL/df) == <render, dL_dout>  (bg = 0)
+    gpu.colors = f1
+    gpu.forward()
+    dL = scenes.make_grad_image(32, inp.image_height, inp.image_width, seed=1)
+    grads = gpu.backward(dL)
+    lhs = float((f1.cpu().double().numpy() * grads["dL_dcolors"].astype(np.float64)).sum())
+    rhs = float((gpu.color.cpu().double().numpy() * dL.astype(np.float64)).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(rhs), 1e-9) + 1e-9, (lhs, rhs)
