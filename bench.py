@@ -116,7 +116,6 @@ def main():
             # config 4: sum the per-Gaussian feature gradients of the N views over RCCL/xGMI
             dist.all_reduce(feats.grad, op=dist.ReduceOp.SUM)
         state["radii"] = radii
-        state["fn"] = color.grad_fn
 
     def barrier():
         if dist is not None:
@@ -154,10 +153,13 @@ def main():
                 acc[k] += ms[k]
         _lib.profile_enable(False)
         stages_ms = {k: v / nprof for k, v in acc.items()}
-        # counters of the last step, from the saved opaque buffers
-        fn = state["fn"]
-        num_rendered = fn.num_rendered
-        imgbuf = fn.saved_tensors[9]
+        # counters: one extra (un-timed) native forward whose opaque buffers we can inspect
+        from seganygaussians_amd.rasterizer import rasterize_gaussians_native
+        e = torch.empty(0)
+        with torch.no_grad():
+            num_rendered, _c, _r, _g, _b, imgbuf = rasterize_gaussians_native(
+                C, False, settings.bg, means3D, feats, opac, None, scales, rots, 1.0, e, settings.viewmatrix,
+                settings.projmatrix, cam.tanfovx, cam.tanfovy, H, W, e, 0, settings.campos, False, False)
         _, ioff = _lib.image_layout(W, H)
         tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
         nc = imgbuf[ioff["n_contrib"]:ioff["n_contrib"] + 4 * W * H].view(torch.int32).reshape(H, W)
