@@ -35,12 +35,14 @@ def algorithmic_bytes(c, C):
     """SURVEY.md 8(d) per-stage algorithmic bytes for one view (fp32, C channels)."""
     P, V, R, E, L, N, Tn = c["P"], c["V"], c["R"], c["E"], c["L"], c["N"], c["tiles"]
     p = (c["sort_bits"] + 7) // 8
+    # binning rows keep the REFERENCE algorithm's byte counts (scan / duplicate / 45-bit sort / ranges), mapped
+    # onto the stages of our pipeline that replace them (DESIGN.md "Binning")
     st = {
         "preprocess": 44 * P + 8 * P + 52 * V,
-        "scan": 8 * P,
-        "duplicate": 8 * P + 12 * V + 12 * R,
-        "sort": (24 * p + 8) * R,
-        "ranges": 8 * R + 8 * Tn,
+        "tile_scan": 8 * P,
+        "emit": 8 * P + 12 * V + 12 * R,
+        "tile_sort": (24 * p + 8) * R + 8 * R + 8 * Tn,
+        "depth_sort": 0,
         "blend_fwd": (28 + 4 * C) * E + (4 * C + 8) * N,
         "blend_bwd": (28 + 4 * C) * L + (4 * C + 8) * N + 2 * 4 * (C + 6) * L,
         "grad_zero_init": 4 * (24 + C) * P,

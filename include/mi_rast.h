@@ -46,8 +46,9 @@ typedef char* (*mi_rast_resize_fn)(size_t nbytes, void* user);
 
 /* Replaces CudaRasterizer::Rasterizer::forward (CF/cuda_rasterizer/rasterizer_impl.cu:198-336,
  * declaration rasterizer.h:34-59; DEPTH variant DEPTH/cuda_rasterizer/rasterizer_impl.cu:198-343).
- * Stages: preprocess -> inclusive scan -> (host reads num_rendered) -> duplicate keys -> radix sort
- * -> tile ranges -> per-tile alpha blend.  Writes EVERY element of out_color (and out_mask /
+ * Stages: preprocess (+ per-tile histogram) -> 32-bit depth sort of the Gaussians -> tile scan -> (host
+ * reads num_rendered) -> rank emission -> per-tile LDS sort -> per-tile alpha blend; the resulting
+ * point_list / ranges are identical to the reference's 64-bit (tile|depth) global sort.  Writes EVERY element of out_color (and out_mask /
  * out_depth), so the caller need not zero-fill them.  *num_rendered [host] receives R. */
 int mi_rast_forward(
     mi_rast_resize_fn geometry_buffer, void* geometry_user,
@@ -152,10 +153,11 @@ uint32_t mi_rast_get_higher_msb(uint32_t n);
  * bit-exactly with the oracle.  Each call fills `offsets` (bytes from the buffer start) for the
  * fields listed, and returns the total size in bytes. */
 enum { MI_GEOM_DEPTHS = 0, MI_GEOM_MEANS2D, MI_GEOM_CONIC_OPACITY, MI_GEOM_COV3D, MI_GEOM_RGB,
-       MI_GEOM_CLAMPED, MI_GEOM_TILES_TOUCHED, MI_GEOM_POINT_OFFSETS, MI_GEOM_SCAN_TEMP, MI_GEOM_NFIELDS };
-enum { MI_IMG_FINAL_T = 0, MI_IMG_N_CONTRIB, MI_IMG_RANGES, MI_IMG_TILE_CONSUMED, MI_IMG_NFIELDS };
-enum { MI_BIN_KEYS_UNSORTED = 0, MI_BIN_KEYS, MI_BIN_VALUES_UNSORTED, MI_BIN_POINT_LIST, MI_BIN_SORT_TEMP,
-       MI_BIN_NFIELDS };
+       MI_GEOM_CLAMPED, MI_GEOM_TILES_TOUCHED, MI_GEOM_DEPTH_KEY, MI_GEOM_IDX_IOTA, MI_GEOM_SORTED_KEY,
+       MI_GEOM_SORTED_IDX, MI_GEOM_SORT_TEMP, MI_GEOM_NFIELDS };
+enum { MI_IMG_FINAL_T = 0, MI_IMG_N_CONTRIB, MI_IMG_RANGES, MI_IMG_TILE_CONSUMED, MI_IMG_TILE_COUNT,
+       MI_IMG_TILE_CURSOR, MI_IMG_NUM_RENDERED, MI_IMG_NFIELDS };
+enum { MI_BIN_ENTRIES = 0, MI_BIN_SCRATCH, MI_BIN_POINT_LIST, MI_BIN_NFIELDS };
 size_t mi_rast_geometry_layout(int P, size_t* offsets /* [MI_GEOM_NFIELDS] */);
 size_t mi_rast_image_layout(int width, int height, size_t* offsets /* [MI_IMG_NFIELDS] */);
 size_t mi_rast_binning_layout(int R, size_t* offsets /* [MI_BIN_NFIELDS] */);
@@ -163,7 +165,7 @@ size_t mi_rast_binning_layout(int R, size_t* offsets /* [MI_BIN_NFIELDS] */);
 /* Per-stage HIP-event timing on the caller's stream (bench.py's live roofline measurement).
  * When enabled, forward/backward record events between stages; mi_rast_profile_read synchronises
  * the last call's events and returns elapsed milliseconds per stage. */
-enum { MI_STAGE_PREPROCESS = 0, MI_STAGE_SCAN, MI_STAGE_DUPLICATE, MI_STAGE_SORT, MI_STAGE_RANGES,
+enum { MI_STAGE_PREPROCESS = 0, MI_STAGE_DEPTH_SORT, MI_STAGE_TILE_SCAN, MI_STAGE_EMIT, MI_STAGE_TILE_SORT,
        MI_STAGE_BLEND_FWD, MI_STAGE_BLEND_BWD, MI_STAGE_GEOM_BWD, MI_STAGE_COUNT };
 int mi_rast_profile_enable(int on);
 int mi_rast_profile_read(float* ms /* [MI_STAGE_COUNT] */);

@@ -10,10 +10,10 @@ from .build import LIB_PATH
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 MI_GEOM_FIELDS = ["depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped", "tiles_touched",
-                  "point_offsets", "scan_temp"]
-MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed"]
-MI_BIN_FIELDS = ["keys_unsorted", "keys", "values_unsorted", "point_list", "sort_temp"]
-MI_STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "blend_fwd", "blend_bwd", "geom_bwd"]
+                  "depth_key", "idx_iota", "sorted_key", "sorted_idx", "sort_temp"]
+MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed", "tile_count", "tile_cursor", "num_rendered"]
+MI_BIN_FIELDS = ["entries", "scratch", "point_list"]
+MI_STAGES = ["preprocess", "depth_sort", "tile_scan", "emit", "tile_sort", "blend_fwd", "blend_bwd", "geom_bwd"]
 
 EXPORTS = [
     "mi_rast_forward", "mi_rast_backward", "mi_rast_mark_visible", "mi_rast_mask_forward",

@@ -6,6 +6,7 @@
 // contiguous 768-B span, so every fetched line is fully used.
 #pragma once
 
+#include "binning.h"
 #include "common.h"
 
 namespace mirast {
@@ -112,19 +113,26 @@ __device__ __forceinline__ float3 computeColorFromSH(int idx, int deg, int max_c
 // Forward preprocess: CF/cuda_rasterizer/forward.cu:159-259 (+ in_frustum, auxiliary.h:139-164).
 // `culled_prefiltered` is incremented when prefiltered is set and a point is culled (the reference
 // printf+__trap()s the whole context there; we report an error instead).
+// gfx950 additions (binning.h): writes the 32-bit depth sort key (0xFFFFFFFF for culled Gaussians) and the
+// identity index array for the depth sort, and histograms the tile overlaps into tile_count[] with the
+// wave-balanced rect walk.
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     uint8_t* __restrict__ clamped, const float* __restrict__ cov3D_precomp, int colors_given, ViewParams vp,
     int* __restrict__ radii, float2* __restrict__ points_xy_image, float* __restrict__ depths,
     float* __restrict__ cov3Ds, float* __restrict__ rgb, float4* __restrict__ conic_opacity,
-    uint32_t* __restrict__ tiles_touched, int prefiltered, int* __restrict__ culled_prefiltered)
+    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ idx_iota,
+    uint32_t* __restrict__ tile_count, int prefiltered, int* __restrict__ culled_prefiltered)
 {
+    __shared__ uint32_t s_prefix[4][64], s_rx[4][64], s_ry[4][64];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int my_radii = 0;
     uint32_t my_tiles = 0;
-    do {
+    uint32_t my_key = 0xFFFFFFFFu;
+    uint2 rect_min = make_uint2(0, 0), rect_max = make_uint2(0, 0);
+    if (idx < P) do {
         const float3 p_orig = make_float3(orig_points[3 * idx], orig_points[3 * idx + 1], orig_points[3 * idx + 2]);
         const float3 p_view = transformPoint4x3(p_orig, vp.view);
         if (p_view.z <= 0.2f) {  // auxiliary.h:154
@@ -158,9 +166,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
         const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
         const float2 point_image = make_float2(ndc2Pix(p_proj.x, vp.W), ndc2Pix(p_proj.y, vp.H));
-        uint2 rect_min, rect_max;
-        getRect(point_image.x, point_image.y, f2i(my_radius), rect_min, rect_max, vp.grid_x, vp.grid_y);
-        if ((rect_max.x - rect_min.x) * (rect_max.y - rect_min.y) == 0) break;
+        uint2 rmin, rmax;
+        getRect(point_image.x, point_image.y, f2i(my_radius), rmin, rmax, vp.grid_x, vp.grid_y);
+        if ((rmax.x - rmin.x) * (rmax.y - rmin.y) == 0) break;
 
         if (!colors_given) {
             const float3 col = computeColorFromSH(idx, D, M, p_orig, vp, shs, clamped);
@@ -172,10 +180,26 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         my_radii = f2i(my_radius);
         points_xy_image[idx] = point_image;
         conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, opacities[idx]);
-        my_tiles = (rect_max.y - rect_min.y) * (rect_max.x - rect_min.x);
+        my_tiles = (rmax.y - rmin.y) * (rmax.x - rmin.x);
+        // A Gaussian whose radius converts to <= 0 is "invisible" for every later stage (radii > 0 tests,
+        // rasterizer_impl.cu:84, backward.cu:156,369) although tiles_touched is nonzero; keep that.
+        if (my_radii > 0) {
+            // duplicateWithKeys recomputes the rect from the stored int radius (rasterizer_impl.cu:91)
+            getRect(point_image.x, point_image.y, my_radii, rect_min, rect_max, vp.grid_x, vp.grid_y);
+            my_key = __float_as_uint(p_view.z);
+        }
     } while (0);
-    radii[idx] = my_radii;
-    tiles_touched[idx] = my_tiles;
+    if (idx < P) {
+        radii[idx] = my_radii;
+        tiles_touched[idx] = my_tiles;
+        depth_key[idx] = my_key;
+        idx_iota[idx] = (uint32_t)idx;
+    }
+    const uint32_t count = (rect_max.x - rect_min.x) * (rect_max.y - rect_min.y);
+    if (ballot64(count != 0) == 0) return;
+    RectWork rw{s_prefix[wave], s_rx[wave], s_ry[wave]};
+    for_each_tile_balanced(rw, lane, rect_min, rect_max, count, vp.grid_x,
+                           [&](uint32_t, uint32_t tile) { atomicAdd(&tile_count[tile], 1u); });
 }
 
 // CF/cuda_rasterizer/rasterizer_impl.cu:54-66

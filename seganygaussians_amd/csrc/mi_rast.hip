@@ -58,19 +58,29 @@ struct Carver {
     }
 };
 
-size_t scan_temp_bytes(int P)
+size_t depth_sort_temp_bytes(int P)
 {
     size_t n = 0;
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, n, (uint32_t*)nullptr, (uint32_t*)nullptr, P > 0 ? P : 1);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, n, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, P > 0 ? P : 1);
     return n;
 }
-size_t sort_temp_bytes(int R)
-{
-    size_t n = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, n, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, R > 0 ? R : 1);
-    return n;
-}
+
+// ---- host-side scratch for the num_rendered read-back: pinned word + event, one per host thread -------
+struct HostSync {
+    int* pinned = nullptr;
+    hipEvent_t ev = nullptr;
+    bool ok = false;
+    bool init()
+    {
+        if (ok) return true;
+        if (hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+};
+thread_local HostSync g_host_sync;
 
 // ---- per-stage profiling (bench.py) -----------------------------------------------------------
 bool g_profile = false;
@@ -122,23 +132,26 @@ struct GeomPtrs {
     float* rgb;
     uint8_t* clamped;
     uint32_t* tiles_touched;
-    uint32_t* point_offsets;
-    char* scan_temp;
-    size_t scan_temp_size;
+    uint32_t* depth_key;
+    uint32_t* idx_iota;
+    uint32_t* sorted_key;
+    uint32_t* sorted_idx;
+    char* sort_temp;
+    size_t sort_temp_size;
 };
 struct ImgPtrs {
     float* final_T;
     uint32_t* n_contrib;
     uint2* ranges;
     uint32_t* tile_consumed;  // per tile: list entries the forward blend consumed (counter E of SURVEY.md 8d)
+    uint32_t* tile_count;
+    uint32_t* tile_cursor;
+    int* num_rendered;
 };
 struct BinPtrs {
-    uint64_t* keys_unsorted;
-    uint64_t* keys;
-    uint32_t* values_unsorted;
+    uint32_t* entries;   // per overlap: depth rank of the Gaussian, bucketed by tile (unsorted inside a tile)
+    uint32_t* scratch;   // ping-pong buffer for tiles too long for the LDS sort
     uint32_t* point_list;
-    char* sort_temp;
-    size_t sort_temp_size;
 };
 
 GeomPtrs geom_from(char* base, int P)
@@ -153,9 +166,12 @@ GeomPtrs geom_from(char* base, int P)
     g.rgb = (float*)(base + off[MI_GEOM_RGB]);
     g.clamped = (uint8_t*)(base + off[MI_GEOM_CLAMPED]);
     g.tiles_touched = (uint32_t*)(base + off[MI_GEOM_TILES_TOUCHED]);
-    g.point_offsets = (uint32_t*)(base + off[MI_GEOM_POINT_OFFSETS]);
-    g.scan_temp = base + off[MI_GEOM_SCAN_TEMP];
-    g.scan_temp_size = scan_temp_bytes(P);
+    g.depth_key = (uint32_t*)(base + off[MI_GEOM_DEPTH_KEY]);
+    g.idx_iota = (uint32_t*)(base + off[MI_GEOM_IDX_IOTA]);
+    g.sorted_key = (uint32_t*)(base + off[MI_GEOM_SORTED_KEY]);
+    g.sorted_idx = (uint32_t*)(base + off[MI_GEOM_SORTED_IDX]);
+    g.sort_temp = base + off[MI_GEOM_SORT_TEMP];
+    g.sort_temp_size = depth_sort_temp_bytes(P);
     return g;
 }
 ImgPtrs img_from(char* base, int W, int H)
@@ -167,6 +183,9 @@ ImgPtrs img_from(char* base, int W, int H)
     m.n_contrib = (uint32_t*)(base + off[MI_IMG_N_CONTRIB]);
     m.ranges = (uint2*)(base + off[MI_IMG_RANGES]);
     m.tile_consumed = (uint32_t*)(base + off[MI_IMG_TILE_CONSUMED]);
+    m.tile_count = (uint32_t*)(base + off[MI_IMG_TILE_COUNT]);
+    m.tile_cursor = (uint32_t*)(base + off[MI_IMG_TILE_CURSOR]);
+    m.num_rendered = (int*)(base + off[MI_IMG_NUM_RENDERED]);
     return m;
 }
 BinPtrs bin_from(char* base, int R)
@@ -174,12 +193,9 @@ BinPtrs bin_from(char* base, int R)
     size_t off[MI_BIN_NFIELDS];
     mi_rast_binning_layout(R, off);
     BinPtrs b;
-    b.keys_unsorted = (uint64_t*)(base + off[MI_BIN_KEYS_UNSORTED]);
-    b.keys = (uint64_t*)(base + off[MI_BIN_KEYS]);
-    b.values_unsorted = (uint32_t*)(base + off[MI_BIN_VALUES_UNSORTED]);
+    b.entries = (uint32_t*)(base + off[MI_BIN_ENTRIES]);
+    b.scratch = (uint32_t*)(base + off[MI_BIN_SCRATCH]);
     b.point_list = (uint32_t*)(base + off[MI_BIN_POINT_LIST]);
-    b.sort_temp = base + off[MI_BIN_SORT_TEMP];
-    b.sort_temp_size = sort_temp_bytes(R);
     return b;
 }
 
@@ -203,15 +219,17 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (!img_base) return fail(MI_RAST_ERR_ALLOC, "image buffer callback returned NULL");
     img = img_from(img_base, W, H);
 
-    // point_offsets[P] doubles as the prefiltered-cull counter slot (scan temp is not live yet)
-    int* cull_counter = (int*)geom.scan_temp;
+    // the depth-sort temp area is not live yet: its first word is the prefiltered-cull counter
+    int* cull_counter = (int*)geom.sort_temp;
     if (prefiltered) HIP_TRY(hipMemsetAsync(cull_counter, 0, sizeof(int), stream));
+    const int ntiles = (int)(vp.grid_x * vp.grid_y);
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
+        HIP_TRY(hipMemsetAsync(img.tile_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
-                           prefiltered, cull_counter);
+                           geom.depth_key, geom.idx_iota, img.tile_count, prefiltered, cull_counter);
     }
     STAGE_CHECK("preprocess");
     if (prefiltered) {
@@ -222,16 +240,26 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             return fail(MI_RAST_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");
     }
     {
-        StageTimer t(stream, MI_STAGE_SCAN);
-        HIP_TRY(hipcub::DeviceScan::InclusiveSum(geom.scan_temp, geom.scan_temp_size, geom.tiles_touched,
-                                                 geom.point_offsets, P, stream));
+        // tile scan first: it only needs tile_count, and its result (R) is what the host waits for; the depth
+        // sort of the Gaussians is queued behind it and overlaps the host round trip + buffer allocation.
+        StageTimer t(stream, MI_STAGE_TILE_SCAN);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, ntiles, img.tile_count, img.ranges,
+                           img.tile_cursor, img.num_rendered);
     }
-    STAGE_CHECK("scan");
-
-    // rasterizer_impl.cu:280-281: the host needs num_rendered to size the binning buffer
-    int R = 0;
-    HIP_TRY(hipMemcpyAsync(&R, geom.point_offsets + P - 1, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    STAGE_CHECK("tile scan");
+    if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host word / event");
+    HIP_TRY(hipMemcpyAsync(g_host_sync.pinned, img.num_rendered, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
+    {
+        StageTimer t(stream, MI_STAGE_DEPTH_SORT);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(geom.sort_temp, geom.sort_temp_size, geom.depth_key, geom.sorted_key,
+                                                   geom.idx_iota, geom.sorted_idx, P, 0, 32, stream));
+    }
+    STAGE_CHECK("depth sort");
+    // rasterizer_impl.cu:280-281: the host needs num_rendered to size the binning buffer.  We wait only for
+    // the copy (event), not for the depth sort queued behind it.
+    HIP_TRY(hipEventSynchronize(g_host_sync.ev));
+    const int R = *g_host_sync.pinned;
     *num_rendered = R;
 
     size_t boff[MI_BIN_NFIELDS];
@@ -239,30 +267,25 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     char* bin_base = binning_buffer(bin_size, binning_user);
     if (!bin_base) return fail(MI_RAST_ERR_ALLOC, "binning buffer callback returned NULL");
     bin = bin_from(bin_base, R);
-
-    {
-        StageTimer t(stream, MI_STAGE_DUPLICATE);
-        hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.means2D,
-                           geom.depths, geom.point_offsets, bin.keys_unsorted, bin.values_unsorted, radii, vp.grid_x,
-                           vp.grid_y);
-    }
-    STAGE_CHECK("duplicateWithKeys");
-
-    const int bit = (int)mi_rast_get_higher_msb(vp.grid_x * vp.grid_y);
     if (R > 0) {
-        StageTimer t(stream, MI_STAGE_SORT);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, bin.sort_temp_size, bin.keys_unsorted, bin.keys,
-                                                   bin.values_unsorted, bin.point_list, R, 0, 32 + bit, stream));
+        {
+            StageTimer t(stream, MI_STAGE_EMIT);
+            hipLaunchKernelGGL(emit_ranks_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.sorted_idx,
+                               geom.means2D, radii, img.ranges, img.tile_cursor, bin.entries, vp.grid_x, vp.grid_y);
+        }
+        STAGE_CHECK("emit ranks");
+        int rank_bits = 1;
+        while ((1ll << rank_bits) < (long long)P) rank_bits++;
+        const int passes = (rank_bits + 7) / 8;
+        {
+            StageTimer t(stream, MI_STAGE_TILE_SORT);
+            hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
+                               bin.entries, bin.scratch, geom.sorted_idx, bin.point_list, passes);
+            hipLaunchKernelGGL((tile_sort_kernel<2048, 12288, true>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
+                               bin.entries, bin.scratch, geom.sorted_idx, bin.point_list, passes);
+        }
+        STAGE_CHECK("tile sort");
     }
-    STAGE_CHECK("sort");
-    {
-        StageTimer t(stream, MI_STAGE_RANGES);
-        HIP_TRY(hipMemsetAsync(img.ranges, 0, (size_t)vp.grid_x * vp.grid_y * sizeof(uint2), stream));
-        if (R > 0)
-            hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, bin.keys,
-                               img.ranges);
-    }
-    STAGE_CHECK("identifyTileRanges");
     return MI_RAST_OK;
 }
 
@@ -326,8 +349,11 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_RGB] = c.take(p * 3 * sizeof(float));
     off[MI_GEOM_CLAMPED] = c.take(p * 3);
     off[MI_GEOM_TILES_TOUCHED] = c.take(p * sizeof(uint32_t));
-    off[MI_GEOM_POINT_OFFSETS] = c.take(p * sizeof(uint32_t));
-    off[MI_GEOM_SCAN_TEMP] = c.take(scan_temp_bytes(P) + 16);
+    off[MI_GEOM_DEPTH_KEY] = c.take(p * sizeof(uint32_t));
+    off[MI_GEOM_IDX_IOTA] = c.take(p * sizeof(uint32_t));
+    off[MI_GEOM_SORTED_KEY] = c.take(p * sizeof(uint32_t));
+    off[MI_GEOM_SORTED_IDX] = c.take(p * sizeof(uint32_t));
+    off[MI_GEOM_SORT_TEMP] = c.take(depth_sort_temp_bytes(P) + 16);
     return c.off;
 }
 size_t mi_rast_image_layout(int width, int height, size_t* off)
@@ -339,17 +365,18 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     off[MI_IMG_N_CONTRIB] = c.take(n * sizeof(uint32_t));
     off[MI_IMG_RANGES] = c.take((tiles ? tiles : 1) * sizeof(uint2));
     off[MI_IMG_TILE_CONSUMED] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
+    off[MI_IMG_TILE_COUNT] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
+    off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
+    off[MI_IMG_NUM_RENDERED] = c.take(16);
     return c.off;
 }
 size_t mi_rast_binning_layout(int R, size_t* off)
 {
     const size_t r = R > 0 ? (size_t)R : 1;
     Carver c;
-    off[MI_BIN_KEYS_UNSORTED] = c.take(r * sizeof(uint64_t));
-    off[MI_BIN_KEYS] = c.take(r * sizeof(uint64_t));
-    off[MI_BIN_VALUES_UNSORTED] = c.take(r * sizeof(uint32_t));
+    off[MI_BIN_ENTRIES] = c.take(r * sizeof(uint32_t));
+    off[MI_BIN_SCRATCH] = c.take(r * sizeof(uint32_t));
     off[MI_BIN_POINT_LIST] = c.take(r * sizeof(uint32_t));
-    off[MI_BIN_SORT_TEMP] = c.take(sort_temp_bytes(R));
     return c.off;
 }
 

@@ -136,16 +136,26 @@ class GpuRun:
                     rgb=self._view(self.geom, off["rgb"], 3 * P, np.float32),
                     clamped=self._view(self.geom, off["clamped"], 3 * P, np.uint8),
                     tiles_touched=self._view(self.geom, off["tiles_touched"], P, np.uint32),
-                    point_offsets=self._view(self.geom, off["point_offsets"], P, np.uint32))
+                    depth_key=self._view(self.geom, off["depth_key"], P, np.uint32),
+                    sorted_idx=self._view(self.geom, off["sorted_idx"], P, np.uint32))
 
     def bin_fields(self):
         from seganygaussians_amd import _lib
         R = self.num_rendered
         _, off = _lib.binning_layout(R)
-        return dict(keys_unsorted=self._view(self.binning, off["keys_unsorted"], R, np.uint64),
-                    keys=self._view(self.binning, off["keys"], R, np.uint64),
-                    values_unsorted=self._view(self.binning, off["values_unsorted"], R, np.uint32),
-                    point_list=self._view(self.binning, off["point_list"], R, np.uint32))
+        return dict(point_list=self._view(self.binning, off["point_list"], R, np.uint32))
+
+    def sorted_keys(self):
+        """The reference's sorted 64-bit key list (tile << 32 | depth bits), which our pipeline never
+        materialises, reconstructed from ranges + point_list + depth bits."""
+        im, pl = self.img_fields(), self.bin_fields()["point_list"]
+        ranges = im["ranges"].reshape(-1, 2).astype(np.int64)
+        counts = ranges[:, 1] - ranges[:, 0]
+        tiles = np.repeat(np.arange(len(ranges), dtype=np.uint64), counts)
+        order = np.argsort(np.repeat(ranges[:, 0], counts), kind="stable")   # list positions ascend with tile id
+        assert np.array_equal(order, np.arange(len(order)))
+        dbits = self.geom_fields()["depths"].view(np.uint32)[pl].astype(np.uint64)
+        return (tiles << np.uint64(32)) | dbits
 
     def img_fields(self):
         from seganygaussians_amd import _lib
@@ -183,13 +193,12 @@ def assert_close(name, got, want, rtol=RTOL, flip_frac=0.0):
 
 
 def compare_integer_path(gpu: GpuRun, fwd: so.ForwardOut):
-    """Bit-exact: radii, tiles_touched, point_offsets, num_rendered, unsorted + sorted (key,value) lists, ranges."""
+    """Bit-exact: radii, tiles_touched, num_rendered, sorted (key,value) list, tile ranges."""
     st = fwd.state
     np.testing.assert_array_equal(gpu.radii.cpu().numpy(), fwd.radii, err_msg="radii")
     assert gpu.num_rendered == fwd.num_rendered, (gpu.num_rendered, fwd.num_rendered)
     g = gpu.geom_fields()
     np.testing.assert_array_equal(g["tiles_touched"], st.field(so.F_TILES_TOUCHED), err_msg="tiles_touched")
-    np.testing.assert_array_equal(g["point_offsets"], st.field(so.F_POINT_OFFSETS), err_msg="point_offsets")
     vis = fwd.radii > 0
     # depths / means2D feed the integer path (key bits, rects): bit-exact where the Gaussian is visible
     np.testing.assert_array_equal(g["depths"].view(np.uint32)[vis], st.field(so.F_DEPTHS).view(np.uint32)[vis],
@@ -197,12 +206,11 @@ def compare_integer_path(gpu: GpuRun, fwd: so.ForwardOut):
     np.testing.assert_array_equal(g["means2D"].view(np.uint32).reshape(-1, 2)[vis],
                                   st.field(so.F_MEANS2D).view(np.uint32).reshape(-1, 2)[vis], err_msg="means2D bits")
     b = gpu.bin_fields()
-    np.testing.assert_array_equal(b["keys_unsorted"], st.field(so.F_KEYS_UNSORTED), err_msg="keys_unsorted")
-    np.testing.assert_array_equal(b["values_unsorted"], st.field(so.F_VALUES_UNSORTED), err_msg="values_unsorted")
-    np.testing.assert_array_equal(b["keys"], st.field(so.F_KEYS_SORTED), err_msg="sorted keys")
     np.testing.assert_array_equal(b["point_list"], st.field(so.F_POINT_LIST), err_msg="point_list")
     im = gpu.img_fields()
     np.testing.assert_array_equal(im["ranges"], st.field(so.F_RANGES), err_msg="tile ranges")
+    if gpu.num_rendered:
+        np.testing.assert_array_equal(gpu.sorted_keys(), st.field(so.F_KEYS_SORTED), err_msg="sorted (tile|depth) keys")
 
 
 def compare_float_forward(gpu: GpuRun, fwd: so.ForwardOut, flip_frac=FLIP_FRAC):
