@@ -21,6 +21,7 @@
 #pragma once
 
 #include "common.h"
+#include "cull.h"
 
 namespace mirast {
 
@@ -214,22 +215,82 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
     __syncthreads();
 }
 
+// A survivor of the exact-conservative cull (cull.h), as the blend kernels consume it: everything needed to
+// evaluate the Gaussian at a pixel in ONE coalesced 32-byte record (the reference gathers id -> xy -> conic
+// per batch with dependent loads, forward.cu:318-326).
+struct __attribute__((aligned(16))) BlendRec {
+    float2 xy;       // pixel-space mean
+    uint32_t id;     // Gaussian index (feature row)
+    uint32_t pm;     // (position in the tile list) << 4 | quadrant mask
+    float4 co;       // conic A,B,C + opacity
+};
+static_assert(sizeof(BlendRec) == 32, "BlendRec must be 32 bytes");
+
+// Emits point_list (the reference-exact sorted id list) and, in the same pass, the compacted blend list of the
+// tile: entries whose quadrant mask is non-zero, in list order, at blend_rec[range.x ...], count in blend_count.
+template <typename SrcPtr>
+__device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_ranks, int n, uint2 range, int tid,
+                                                const uint32_t* __restrict__ sorted_idx,
+                                                const float2* __restrict__ points_xy,
+                                                const float4* __restrict__ conic_opacity,
+                                                uint32_t* __restrict__ point_list, BlendRec* __restrict__ blend_rec,
+                                                uint32_t* __restrict__ blend_count, uint32_t tile, uint32_t gx,
+                                                uint32_t* s_wcount)
+{
+    const int wave = tid >> 6;
+    const float tile_px = (float)((tile % gx) * TILE_X), tile_py = (float)((tile / gx) * TILE_Y);
+    uint32_t* out = point_list + range.x;
+    BlendRec* rec = blend_rec + range.x;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        uint32_t g = 0, qmask = 0;
+        float2 xy = make_float2(0.f, 0.f);
+        float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+            g = sorted_idx[sorted_ranks[i]];
+            out[i] = g;
+            xy = points_xy[g];
+            co = conic_opacity[g];
+            qmask = quadrant_mask(xy, co, tile_px, tile_py);
+        }
+        int ns;
+        const int slot = compact_slot(qmask != 0, wave, s_wcount, ns);
+        if (slot >= 0) {
+            BlendRec r;
+            r.xy = xy;
+            r.id = g;
+            r.pm = ((uint32_t)i << 4) | qmask;
+            r.co = co;
+            rec[base + slot] = r;
+        }
+        base += ns;
+        __syncthreads();  // s_wcount reuse
+    }
+    if (tid == 0) blend_count[tile] = (uint32_t)base;
+}
+
 template <int LO, int CAP, bool GLOBAL_FALLBACK>
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ entries,
                                                         uint32_t* __restrict__ scratch,
                                                         const uint32_t* __restrict__ sorted_idx,
-                                                        uint32_t* __restrict__ point_list, int passes)
+                                                        uint32_t* __restrict__ point_list, int passes,
+                                                        const float2* __restrict__ points_xy,
+                                                        const float4* __restrict__ conic_opacity,
+                                                        BlendRec* __restrict__ blend_rec,
+                                                        uint32_t* __restrict__ blend_count, uint32_t gx)
 {
     __shared__ uint32_t s_a[CAP];
     __shared__ uint32_t s_b[CAP];
     __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_wcount[4];
     const int tid = threadIdx.x;
     const uint2 range = ranges[blockIdx.x];
     const int n = (int)(range.y - range.x);
+    if (LO == 0 && n == 0 && tid == 0) blend_count[blockIdx.x] = 0u;
     if (n <= LO) return;
     if (n > CAP && !GLOBAL_FALLBACK) return;
     uint32_t* seg = entries + range.x;
-    uint32_t* out = point_list + range.x;
     if (n <= CAP) {
         for (int i = tid; i < n; i += 256) s_a[i] = seg[i];
         __syncthreads();
@@ -241,7 +302,8 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
             a = b;
             b = t;
         }
-        for (int i = tid; i < n; i += 256) out[i] = sorted_idx[a[i]];
+        emit_tile_lists(a, n, range, tid, sorted_idx, points_xy, conic_opacity, point_list, blend_rec, blend_count,
+                        blockIdx.x, gx, s_wcount);
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
@@ -251,7 +313,8 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
             a = b;
             b = t;
         }
-        for (int i = tid; i < n; i += 256) out[i] = sorted_idx[a[i]];
+        emit_tile_lists(a, n, range, tid, sorted_idx, points_xy, conic_opacity, point_list, blend_rec, blend_count,
+                        blockIdx.x, gx, s_wcount);
     }
 }
 

@@ -5,19 +5,26 @@
 // no background term); with C==0, EXTRA==1 the mask-only render (DEPTH/.../forward.cu:390-498).
 //
 // gfx950 mapping: one 256-thread workgroup per 16x16 tile (the tile size is part of the integer
-// contract), four wave64s each owning an 8x8 pixel quadrant so that "no lane of this wave is
-// touched by this Gaussian" is a frequent, wave-uniform (scalar-branch) skip.  The per-tile list is
-// staged 256 entries at a time through LDS: geometry (xy, conic+opacity) AND the C feature floats of
-// every staged Gaussian, with coalesced 16-B loads (8 lanes cover one Gaussian's 128 B at C=32), so
-// the inner loop reads features as LDS broadcasts instead of the reference's per-pixel global loads.
+// contract), four wave64s each owning an 8x8 pixel quadrant.  The kernel does not walk the raw tile list:
+// it streams the tile's BLEND LIST (binning.h), i.e. only the entries that can reach alpha >= 1/255
+// somewhere in the tile (about one third of the list on the benchmark scene), as coalesced 32-byte records
+// that already hold xy / conic / opacity / id / list position / quadrant mask -- no dependent gathers.
+// Per batch of FB records:
+//   A. record -> LDS; the NEXT batch's record is already in flight in registers while this one is blended;
+//   B. the C feature floats of every record are staged into LDS with coalesced 16-B loads (8 lanes cover one
+//      Gaussian's 128 B at C=32) -- the reference re-reads features from global memory per pixel (forward.cu:359);
+//   C. each wave walks the records, skipping those whose mask bit for its quadrant is clear (scalar test),
+//      with the next record's geometry prefetched from LDS while the current one is blended.
 // Early termination is per wave (ballot) and per workgroup (__syncthreads_and).
 #pragma once
 
+#include "binning.h"
 #include "common.h"
 
 namespace mirast {
 
-constexpr int BATCH = 256;
+constexpr int BATCH = 256;  // threads per tile workgroup
+constexpr int FB = 128;     // blend-list records per forward batch
 
 template <int CE>
 struct FeatStage {
@@ -27,26 +34,30 @@ struct FeatStage {
 
 template <int C, int EXTRA>
 __global__ void __launch_bounds__(256) blend_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
-    const float2* __restrict__ points_xy_image, const float* __restrict__ features,
-    const float4* __restrict__ conic_opacity, const float* __restrict__ mask, const float* __restrict__ depths,
+    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
+    int W, int H, const float* __restrict__ features, const float* __restrict__ mask, const float* __restrict__ depths,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed,
-    const float* __restrict__ bg_color,
-    float* __restrict__ out_color, float* __restrict__ out_mask, float* __restrict__ out_depth)
+    uint32_t* __restrict__ tile_nsurv, const float* __restrict__ bg_color, float* __restrict__ out_color,
+    float* __restrict__ out_mask, float* __restrict__ out_depth,
+    int ablate /* timing experiments only (MI_RAST_ABLATE_FWD); 0 in production */)
 {
     constexpr int CE = C + EXTRA;            // accumulated values per pixel
     constexpr int ROW = FeatStage<CE>::ROW;  // LDS floats per staged Gaussian
     constexpr bool VEC_STAGE = (EXTRA == 0) && (C % 4 == 0) && (C >= 4);
 
-    __shared__ int s_id[BATCH];
-    __shared__ float2 s_xy[BATCH];
-    __shared__ float4 s_co[BATCH];
-    __shared__ float4 s_feat4[BATCH * ROW / 4];
-    __shared__ int s_consumed;
+    __shared__ float2 s_xy[FB];
+    __shared__ float4 s_co[FB];
+    __shared__ uint32_t s_id[FB];
+    __shared__ uint32_t s_pm[FB];  // (position in the tile list) << 4 | quadrant mask
+    __shared__ float4 s_feat4[FB * ROW / 4];
+    __shared__ int s_consumed, s_walked;
     float* s_feat = reinterpret_cast<float*>(s_feat4);
 
     const int tid = threadIdx.x;
-    if (tid == 0) s_consumed = 0;
+    if (tid == 0) {
+        s_consumed = 0;
+        s_walked = 0;
+    }
     const int wave = tid >> 6, lane = tid & 63;
     const uint32_t horizontal_blocks = (W + TILE_X - 1) / TILE_X;
     const uint32_t tile = blockIdx.y * horizontal_blocks + blockIdx.x;
@@ -59,74 +70,104 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     bool done = !inside;
 
     const uint2 range = ranges[tile];
-    int toDo = range.y - range.x;
-    const int rounds = (toDo + BATCH - 1) / BATCH;
+    const int list_len = (int)(range.y - range.x);
+    const int ns_total = (int)blend_count[tile];
+    const BlendRec* rec = blend_rec + range.x;
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
-    int consumed = 0;  // wave-uniform: list entries this wave walked
+    // wave-uniform counters: raw list entries this wave walked (counter E of SURVEY.md 8d: a wave that never
+    // finishes walks the whole list) and blend-list records it walked (the backward starts from there)
+    int consumed = (ballot64(!done) != 0) ? list_len : 0;
+    int walked = 0;
     float acc[CE > 0 ? CE : 1];
 #pragma unroll
     for (int ch = 0; ch < CE; ch++) acc[ch] = 0.f;
 
-    for (int i = 0; i < rounds; i++, toDo -= BATCH) {
+    BlendRec cur;
+    if (tid < FB && tid < ns_total) cur = rec[tid];
+
+    for (int b0 = 0; b0 < ns_total; b0 += FB) {
         // whole workgroup finished? (also the barrier that protects LDS reuse)
         if (__syncthreads_and(done)) break;
+        const int nb = min(FB, ns_total - b0);
 
-        const int progress = i * BATCH + tid;
-        if (range.x + progress < range.y) {
-            const int coll_id = point_list[range.x + progress];
-            s_id[tid] = coll_id;
-            s_xy[tid] = points_xy_image[coll_id];
-            s_co[tid] = conic_opacity[coll_id];
+        // ---- A: this batch's records -> LDS; next batch's records -> registers (in flight during B and C)
+        if (tid < nb) {
+            s_xy[tid] = cur.xy;
+            s_co[tid] = cur.co;
+            s_id[tid] = cur.id;
+            s_pm[tid] = cur.pm;
             if constexpr (!VEC_STAGE) {
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) s_feat[tid * ROW + ch] = features[(size_t)coll_id * C + ch];
-                if constexpr (EXTRA >= 1) s_feat[tid * ROW + C] = mask[coll_id];
-                if constexpr (EXTRA >= 2) s_feat[tid * ROW + C + 1] = depths[coll_id];
+                for (int ch = 0; ch < C; ch++) s_feat[tid * ROW + ch] = features[(size_t)cur.id * C + ch];
+                if constexpr (EXTRA >= 1) s_feat[tid * ROW + C] = mask[cur.id];
+                if constexpr (EXTRA >= 2) s_feat[tid * ROW + C + 1] = depths[cur.id];
+            }
+        }
+        if (tid < FB && b0 + FB + tid < ns_total) cur = rec[b0 + FB + tid];
+        if constexpr (VEC_STAGE) {
+            // ---- B: features (ids straight from the records: thread q reads record q / F4)
+            constexpr int F4 = C / 4;  // float4s per Gaussian
+            if (!(ablate & 4))
+#pragma unroll
+            for (int k = 0; k < FB * F4 / BATCH; k++) {
+                const int q = tid + BATCH * k;
+                const int g = q / F4, part = q % F4;
+                if (g < nb) s_feat4[g * F4 + part] = reinterpret_cast<const float4*>(features + (size_t)rec[b0 + g].id * C)[part];
             }
         }
         __syncthreads();
-        const int nb = toDo < BATCH ? toDo : BATCH;
-        if constexpr (VEC_STAGE) {
-            constexpr int F4 = C / 4;  // float4s per Gaussian
+
+        // ---- C: blend
+        if (ballot64(!done) != 0) {
+            walked = b0 + nb;
+            float2 nxy = s_xy[0];
+            float4 nco = s_co[0];
+            uint32_t npm = s_pm[0];
+            for (int k = 0; k < nb; k++) {
+                const float2 cxy = nxy;
+                const float4 cco = nco;
+                const uint32_t pm = __builtin_amdgcn_readfirstlane(npm);
+                const int kn = k + 1 < nb ? k + 1 : k;  // prefetch the next record
+                nxy = s_xy[kn];
+                nco = s_co[kn];
+                npm = s_pm[kn];
+                if (!((pm >> wave) & 1u)) continue;  // culled for this quadrant
+                if (ablate & 2) continue;
+                const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
+                const float power = -0.5f * (cco.x * dx * dx + cco.z * dy * dy) - cco.y * dx * dy;
+                const float alpha = fminf(0.99f, cco.w * __expf(power));
+                const bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                const float test_T = T * (1 - alpha);
+                const bool stop = ok && test_T < 0.0001f;
+                done = done || stop;
+                const bool blend = ok && !stop;
+                if (ballot64(blend) != 0) {
+                    const float w = blend ? alpha * T : 0.f;
+                    if (!(ablate & 1))
 #pragma unroll
-            for (int k = 0; k < F4; k++) {
-                const int q = tid + BATCH * k;
-                const int g = q / F4, part = q % F4;
-                if (g < nb) {
-                    const float4 v = reinterpret_cast<const float4*>(features + (size_t)s_id[g] * C)[part];
-                    s_feat4[g * F4 + part] = v;
+                    for (int ch = 0; ch < CE; ch++) acc[ch] = fmaf(s_feat[k * ROW + ch], w, acc[ch]);
+                    T = blend ? test_T : T;
+                    last_contributor = blend ? (pm >> 4) + 1u : last_contributor;
+                }
+                if (ballot64(!done) == 0) {  // this wave is finished
+                    consumed = (int)(pm >> 4) + 1;
+                    walked = b0 + k + 1;
+                    break;
                 }
             }
-            __syncthreads();
-        }
-
-        for (int j = 0; j < nb; j++) {
-            if (ballot64(!done) == 0) break;  // this wave has nothing left to do
-            consumed = i * BATCH + j + 1;
-            const float2 xy = s_xy[j];
-            const float4 con_o = s_co[j];
-            const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-            const float power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;
-            const float alpha = fminf(0.99f, con_o.w * __expf(power));
-            const bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-            const float test_T = T * (1 - alpha);
-            const bool stop = ok && test_T < 0.0001f;
-            done = done || stop;
-            const bool blend = ok && !stop;
-            if (ballot64(blend) == 0) continue;  // wave-uniform: nobody in this 8x8 quadrant is touched
-            const float w = blend ? alpha * T : 0.f;
-#pragma unroll
-            for (int ch = 0; ch < CE; ch++) acc[ch] = fmaf(s_feat[j * ROW + ch], w, acc[ch]);
-            T = blend ? test_T : T;
-            last_contributor = blend ? (uint32_t)(i * BATCH + j + 1) : last_contributor;
         }
     }
-
-    if (lane == 0) atomicMax(&s_consumed, consumed);
+    if (lane == 0) {
+        atomicMax(&s_consumed, consumed);
+        atomicMax(&s_walked, walked);
+    }
     __syncthreads();
-    if (tid == 0) tile_consumed[tile] = (uint32_t)s_consumed;
+    if (tid == 0) {
+        tile_consumed[tile] = (uint32_t)s_consumed;
+        tile_nsurv[tile] = (uint32_t)s_walked;
+    }
     if (inside) {
         final_T[pix_id] = T;
         n_contrib[pix_id] = last_contributor;

@@ -1,0 +1,75 @@
+// cull.h -- exact-conservative per-quadrant culling of tile-list entries + order-preserving compaction.
+//
+// The tile lists (bit-exact contract) are built from the 3-sigma bounding SQUARE of every Gaussian
+// (CF/cuda_rasterizer/forward.cu:232-240), which is very loose for anisotropic or faint Gaussians: on the
+// BASELINE config-3 scene only 1/3 of the consumed list entries blend into ANY pixel of their tile and only
+// 1/4 of the (8x8-quadrant, entry) pairs have a blending pixel.  The reference evaluates all of them for
+// every pixel.  Here, while a batch of 256 entries is staged, the staging thread of each entry evaluates in
+// closed form the MINIMUM over each 8x8 quadrant of  q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy  (convex
+// quadratic over a box: 0 if the mean is inside, else the best of the four clamped edge minima) and keeps
+// the entry for that quadrant only if  min q <= ln(255 * opacity) + margin,  i.e. only if some pixel can
+// reach alpha >= 1/255 (forward.cu:346-347).  The margin (relative to the magnitude of the terms, >> float
+// rounding of both this bound and the kernel's own `power`) keeps the test a strict superset, so the
+// per-pixel arithmetic -- and therefore the result -- is unchanged; culled entries are simply never visited.
+// Survivors are compacted in list order, so front-to-back order and contributor indices are preserved.
+#pragma once
+
+#include "common.h"
+
+namespace mirast {
+
+// min over dy in [lo,hi] of  1/2 C dy^2 + (B dxe) dy + 1/2 A dxe^2   (C > 0)
+__device__ __forceinline__ float edge_min(float A, float B, float C, float rcpC, float dxe, float lo, float hi)
+{
+    const float t = fminf(hi, fmaxf(lo, -B * dxe * rcpC));
+    return 0.5f * (A * dxe * dxe + C * t * t) + B * dxe * t;
+}
+
+// Bit q (= qy*2 + qx) set  <=>  the 8x8 pixel quadrant q of the tile at (tile_px, tile_py) may receive
+// alpha >= 1/255 from this Gaussian.  xy: pixel-space mean; co: conic (A,B,C) + opacity.
+__device__ __forceinline__ uint32_t quadrant_mask(float2 xy, float4 co, float tile_px, float tile_py)
+{
+    const float A = co.x, B = co.y, C = co.z, o = co.w;
+    if (!(o >= (1.0f / 255.0f))) return 0u;  // alpha <= opacity < 1/255 everywhere (also drops NaN opacity)
+    if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return 0xFu;  // not positive definite: no culling
+    const float tau = __logf(255.0f * o);
+    const float rcpA = __builtin_amdgcn_rcpf(A), rcpC = __builtin_amdgcn_rcpf(C);
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float x_lo = tile_px + (float)((q & 1) * 8), y_lo = tile_py + (float)((q >> 1) * 8);
+        // d = mean - pixel, pixel in [x_lo, x_lo+7] x [y_lo, y_lo+7]
+        const float dxl = xy.x - (x_lo + 7.0f), dxh = xy.x - x_lo;
+        const float dyl = xy.y - (y_lo + 7.0f), dyh = xy.y - y_lo;
+        float qmin;
+        if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) {
+            qmin = 0.f;
+        } else {
+            const float e0 = edge_min(A, B, C, rcpC, dxl, dyl, dyh);
+            const float e1 = edge_min(A, B, C, rcpC, dxh, dyl, dyh);
+            const float e2 = edge_min(C, B, A, rcpA, dyl, dxl, dxh);
+            const float e3 = edge_min(C, B, A, rcpA, dyh, dxl, dxh);
+            qmin = fminf(fminf(e0, e1), fminf(e2, e3));
+        }
+        const float mx = fmaxf(fabsf(dxl), fabsf(dxh)), my = fmaxf(fabsf(dyl), fabsf(dyh));
+        const float mag = 0.5f * (A * mx * mx + C * my * my) + fabsf(B) * mx * my;
+        if (!(qmin > tau + 1e-5f * mag + 1e-4f)) mask |= 1u << q;  // NaN -> keep
+    }
+    return mask;
+}
+
+// Order-preserving compaction of one batch: returns this thread's slot (or -1) and the survivor count.
+// s_wcount: LDS uint32[4].  Contains one workgroup barrier.
+__device__ __forceinline__ int compact_slot(bool survive, int wave, uint32_t* s_wcount, int& total)
+{
+    const uint64_t b = ballot64(survive);
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    if ((threadIdx.x & 63) == 0) s_wcount[wave] = (uint32_t)__builtin_popcountll(b);
+    __syncthreads();
+    const uint32_t c0 = s_wcount[0], c1 = s_wcount[1], c2 = s_wcount[2], c3 = s_wcount[3];
+    total = (int)(c0 + c1 + c2 + c3);
+    const uint32_t woff = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
+    return survive ? (int)(woff + below) : -1;
+}
+
+}  // namespace mirast

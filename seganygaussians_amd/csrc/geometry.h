@@ -356,17 +356,27 @@ __device__ __forceinline__ void cov3d_backward(const float3 scale, float mod, co
 __global__ void __launch_bounds__(256) geometry_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii, const float* __restrict__ shs,
     const uint8_t* __restrict__ clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ cov3Ds, ViewParams vp, const float* __restrict__ dL_dmean2D,
-    const float* __restrict__ dL_dconics, float* __restrict__ dL_dmeans, const float* __restrict__ dL_dcolor,
+    const float* __restrict__ cov3Ds, ViewParams vp, const float* __restrict__ gpack /*[P,8] from blend_bwd*/,
+    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconics, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dmask, float* __restrict__ dL_dmeans, const float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dcov, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P || !(radii[idx] > 0)) return;
 
+    // unpack the per-Gaussian record written by the blend backward: {mean2D.x, mean2D.y, conic.x, conic.y,
+    // conic.w, opacity, mask, -} -> the reference's dL_dmean2D (P,3), dL_dconic (P,2,2), dL_dopacity, dL_dmask
+    const float4 g0 = reinterpret_cast<const float4*>(gpack)[2 * idx];
+    const float4 g1 = reinterpret_cast<const float4*>(gpack)[2 * idx + 1];
+    dL_dmean2D[3 * idx + 0] = g0.x;
+    dL_dmean2D[3 * idx + 1] = g0.y;
+    reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(g0.z, g0.w, 0.f, g1.x);
+    dL_dopacity[idx] = g1.y;
+    if (dL_dmask) dL_dmask[idx] = g1.z;
+
     // ---- computeCov2DCUDA, backward.cu:144-274
     const float3 mean = make_float3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]);
-    const float4 dcon4 = reinterpret_cast<const float4*>(dL_dconics)[idx];
-    const float3 dL_dconic = make_float3(dcon4.x, dcon4.y, dcon4.w);
+    const float3 dL_dconic = make_float3(g0.z, g0.w, g1.x);
     float cov3D[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) cov3D[i] = cov3Ds[(size_t)idx * 6 + i];
@@ -435,7 +445,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(
     const float m_w = 1.0f / (m_hom.w + 0.0000001f);
     const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
     const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-    const float gx = dL_dmean2D[3 * idx], gy = dL_dmean2D[3 * idx + 1];
+    const float gx = g0.x, gy = g0.y;
     float3 dm;
     dm.x = (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
     dm.y = (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
@@ -458,6 +468,13 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(
         dL_dscale[3 * idx + 2] = ds.z;
         reinterpret_cast<float4*>(dL_drot)[idx] = dq;
     }
+}
+
+// mask-only pair: dL_dmask[i] = packed field 6
+__global__ void __launch_bounds__(256) unpack_mask_kernel(int P, const float* __restrict__ gpack, float* __restrict__ dL_dmask)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < P) dL_dmask[idx] = gpack[(size_t)idx * 8 + 6];
 }
 
 }  // namespace mirast

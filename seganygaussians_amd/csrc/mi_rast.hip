@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -138,6 +139,7 @@ struct GeomPtrs {
     uint32_t* sorted_idx;
     char* sort_temp;
     size_t sort_temp_size;
+    float* bwd_pack;  // [P,8] packed per-Gaussian field gradients (backward scratch)
 };
 struct ImgPtrs {
     float* final_T;
@@ -147,11 +149,14 @@ struct ImgPtrs {
     uint32_t* tile_count;
     uint32_t* tile_cursor;
     int* num_rendered;
+    uint32_t* blend_count;  // per tile: records in its blend list
+    uint32_t* tile_nsurv;   // per tile: blend-list records the forward walked
 };
 struct BinPtrs {
     uint32_t* entries;   // per overlap: depth rank of the Gaussian, bucketed by tile (unsorted inside a tile)
     uint32_t* scratch;   // ping-pong buffer for tiles too long for the LDS sort
     uint32_t* point_list;
+    BlendRec* blend_rec;  // per tile at range.x: compacted survivor records (binning.h)
 };
 
 GeomPtrs geom_from(char* base, int P)
@@ -172,6 +177,7 @@ GeomPtrs geom_from(char* base, int P)
     g.sorted_idx = (uint32_t*)(base + off[MI_GEOM_SORTED_IDX]);
     g.sort_temp = base + off[MI_GEOM_SORT_TEMP];
     g.sort_temp_size = depth_sort_temp_bytes(P);
+    g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
     return g;
 }
 ImgPtrs img_from(char* base, int W, int H)
@@ -186,6 +192,8 @@ ImgPtrs img_from(char* base, int W, int H)
     m.tile_count = (uint32_t*)(base + off[MI_IMG_TILE_COUNT]);
     m.tile_cursor = (uint32_t*)(base + off[MI_IMG_TILE_CURSOR]);
     m.num_rendered = (int*)(base + off[MI_IMG_NUM_RENDERED]);
+    m.blend_count = (uint32_t*)(base + off[MI_IMG_BLEND_COUNT]);
+    m.tile_nsurv = (uint32_t*)(base + off[MI_IMG_TILE_NSURV]);
     return m;
 }
 BinPtrs bin_from(char* base, int R)
@@ -196,8 +204,13 @@ BinPtrs bin_from(char* base, int R)
     b.entries = (uint32_t*)(base + off[MI_BIN_ENTRIES]);
     b.scratch = (uint32_t*)(base + off[MI_BIN_SCRATCH]);
     b.point_list = (uint32_t*)(base + off[MI_BIN_POINT_LIST]);
+    b.blend_rec = (BlendRec*)(base + off[MI_BIN_BLEND_REC]);
     return b;
 }
+
+// Timing experiments only: MI_RAST_ABLATE=<bitmask> disables pieces of the backward blend (results become wrong).
+int g_ablate = 0;
+int g_ablate_fwd = 0;
 
 bool channels_supported(int c) { return c == 3 || c == 32 || c == 64; }
 
@@ -226,6 +239,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
         HIP_TRY(hipMemsetAsync(img.tile_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(img.blend_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
@@ -280,9 +294,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
             hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                               bin.entries, bin.scratch, geom.sorted_idx, bin.point_list, passes);
+                               bin.entries, bin.scratch, geom.sorted_idx, bin.point_list, passes, geom.means2D,
+                               geom.conic_opacity, bin.blend_rec, img.blend_count, vp.grid_x);
             hipLaunchKernelGGL((tile_sort_kernel<2048, 12288, true>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                               bin.entries, bin.scratch, geom.sorted_idx, bin.point_list, passes);
+                               bin.entries, bin.scratch, geom.sorted_idx, bin.point_list, passes, geom.means2D,
+                               geom.conic_opacity, bin.blend_rec, img.blend_count, vp.grid_x);
         }
         STAGE_CHECK("tile sort");
     }
@@ -295,19 +311,18 @@ void launch_blend_fwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& i
                       float* out_color, float* out_mask, float* out_depth)
 {
     hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                       bin.point_list, vp.W, vp.H, geom.means2D, features, geom.conic_opacity, mask, geom.depths,
-                       img.final_T, img.n_contrib, img.tile_consumed, bg, out_color, out_mask, out_depth);
+                       bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
+                       img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, g_ablate_fwd);
 }
 
 template <int C, bool MASKGRAD>
 void launch_blend_bwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin,
                       const GeomPtrs& geom, const float* colors, const float* bg, const float* dL_dpix,
-                      const float* dL_dout_mask, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                      float* dL_dcolor, float* dL_dmask)
+                      const float* dL_dout_mask, float* dL_dcolor)
 {
     hipLaunchKernelGGL((blend_bwd_kernel<C, MASKGRAD>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                       bin.point_list, vp.W, vp.H, bg, geom.means2D, geom.conic_opacity, colors, img.final_T,
-                       img.n_contrib, dL_dpix, dL_dout_mask, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmask);
+                       bin.blend_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
+                       dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate);
 }
 
 }  // namespace
@@ -354,6 +369,7 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_SORTED_KEY] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_SORTED_IDX] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_SORT_TEMP] = c.take(depth_sort_temp_bytes(P) + 16);
+    off[MI_GEOM_BWD_PACK] = c.take(p * 8 * sizeof(float));
     return c.off;
 }
 size_t mi_rast_image_layout(int width, int height, size_t* off)
@@ -368,6 +384,8 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     off[MI_IMG_TILE_COUNT] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_NUM_RENDERED] = c.take(16);
+    off[MI_IMG_BLEND_COUNT] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
+    off[MI_IMG_TILE_NSURV] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     return c.off;
 }
 size_t mi_rast_binning_layout(int R, size_t* off)
@@ -377,6 +395,7 @@ size_t mi_rast_binning_layout(int R, size_t* off)
     off[MI_BIN_ENTRIES] = c.take(r * sizeof(uint32_t));
     off[MI_BIN_SCRATCH] = c.take(r * sizeof(uint32_t));
     off[MI_BIN_POINT_LIST] = c.take(r * sizeof(uint32_t));
+    off[MI_BIN_BLEND_REC] = c.take(r * sizeof(BlendRec));
     return c.off;
 }
 
@@ -417,6 +436,10 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (num_rendered) *num_rendered = 0;
+    {
+        const char* ab = getenv("MI_RAST_ABLATE_FWD");
+        g_ablate_fwd = ab ? atoi(ab) : 0;
+    }
     if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
     if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
     if (mask && channels != 3) return fail(MI_RAST_ERR_INVALID, "mask/depth variant is built for 3 channels");
@@ -460,6 +483,10 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (P <= 0) return MI_RAST_OK;
+    {
+        const char* ab = getenv("MI_RAST_ABLATE");
+        g_ablate = ab ? atoi(ab) : 0;
+    }
     if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
     const bool maskgrad = dL_dmask != nullptr;
     if (maskgrad && (channels != 3 || !dL_dout_mask)) return fail(MI_RAST_ERR_INVALID, "mask gradient needs 3 channels and dL_dout_mask");
@@ -472,10 +499,11 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     const float* color_ptr = (colors_precomp != nullptr) ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:389
     {
         StageTimer t(stream, MI_STAGE_BLEND_BWD);
-        if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmask);
-        else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, nullptr);
-        else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, nullptr);
-        else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, nullptr);
+        HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float), stream));
+        if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor);
+        else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
+        else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
+        else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
     }
     STAGE_CHECK("render backward");
 
@@ -483,8 +511,8 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     {
         StageTimer t(stream, MI_STAGE_GEOM_BWD);
         hipLaunchKernelGGL(geometry_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, radii, shs,
-                           geom.clamped, scales, rotations, cov3D_ptr, vp, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor,
-                           dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                           geom.clamped, scales, rotations, cov3D_ptr, vp, geom.bwd_pack, dL_dmean2D, dL_dconic, dL_dopacity,
+                           dL_dmask, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     }
     STAGE_CHECK("preprocess backward");
     return MI_RAST_OK;
@@ -547,8 +575,9 @@ int mi_rast_mask_backward(int P, int R, int width, int height, char* geom_buffer
     const ImgPtrs img = img_from(img_buffer, width, height);
     {
         StageTimer t(stream, MI_STAGE_BLEND_BWD);
-        launch_blend_bwd<0, true>(vp, stream, img, bin, geom, nullptr, nullptr, nullptr, dL_dout_mask, nullptr, nullptr,
-                                  nullptr, nullptr, dL_dmask);
+        HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float), stream));
+        launch_blend_bwd<0, true>(vp, stream, img, bin, geom, nullptr, nullptr, nullptr, dL_dout_mask, nullptr);
+        hipLaunchKernelGGL(unpack_mask_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.bwd_pack, dL_dmask);
     }
     STAGE_CHECK("render_mask backward");
     return MI_RAST_OK;
