@@ -15,6 +15,11 @@
 //      Gaussian's 128 B at C=32) -- the reference re-reads features from global memory per pixel (forward.cu:359);
 //   C. each wave walks the records, skipping those whose mask bit for its quadrant is clear (scalar test),
 //      with the next record's geometry prefetched from LDS while the current one is blended.
+// For C = 32 / 64 the accumulation  acc[pixel][ch] += w[pixel] * f[g][ch]  is a rank-1 update and runs on the
+// matrix pipe: v_mfma_f32_32x32x1_2b_f32 takes A = w (lane = pixel: two 32-pixel blocks) and B = f[g][lane & 31]
+// (ONE ds_read_b32 instead of eight broadcast ds_read_b128) and keeps the 64x32 accumulator tile in 32 VGPRs.
+// f32 MFMA is bit-for-bit an fmaf chain, so numerics equal the VALU path; VALU and LDS are left to the alpha
+// evaluation.  The accumulator tile (lane = channel) is transposed through LDS once per tile for the CHW stores.
 // Early termination is per wave (ballot) and per workgroup (__syncthreads_and).
 #pragma once
 
@@ -44,12 +49,17 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     constexpr int CE = C + EXTRA;            // accumulated values per pixel
     constexpr int ROW = FeatStage<CE>::ROW;  // LDS floats per staged Gaussian
     constexpr bool VEC_STAGE = (EXTRA == 0) && (C % 4 == 0) && (C >= 4);
+    constexpr bool USE_MFMA = (EXTRA == 0) && (C == 32 || C == 64);
+    constexpr int NACC = USE_MFMA ? C / 32 : 1;  // 32-channel accumulator tiles
+    typedef float v32f __attribute__((ext_vector_type(32)));
 
     __shared__ float2 s_xy[FB];
     __shared__ float4 s_co[FB];
     __shared__ uint32_t s_id[FB];
     __shared__ uint32_t s_pm[FB];  // (position in the tile list) << 4 | quadrant mask
     __shared__ float4 s_feat4[FB * ROW / 4];
+    __shared__ uint64_t s_bits[4][FB / 64];  // [quadrant][staging wave]: records that may touch the quadrant
+    __shared__ uint8_t s_list[4][FB];        // per quadrant: indices of those records, in list order
     __shared__ int s_consumed, s_walked;
     float* s_feat = reinterpret_cast<float*>(s_feat4);
 
@@ -80,9 +90,17 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     // finishes walks the whole list) and blend-list records it walked (the backward starts from there)
     int consumed = (ballot64(!done) != 0) ? list_len : 0;
     int walked = 0;
-    float acc[CE > 0 ? CE : 1];
+    float acc[(CE > 0 && !USE_MFMA) ? CE : 1];
+    v32f accv[NACC];
+    if constexpr (USE_MFMA) {
 #pragma unroll
-    for (int ch = 0; ch < CE; ch++) acc[ch] = 0.f;
+        for (int a = 0; a < NACC; a++)
+#pragma unroll
+            for (int r = 0; r < 32; r++) accv[a][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < CE; ch++) acc[ch] = 0.f;
+    }
 
     BlendRec cur;
     if (tid < FB && tid < ns_total) cur = rec[tid];
@@ -105,6 +123,15 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                 if constexpr (EXTRA >= 2) s_feat[tid * ROW + C + 1] = depths[cur.id];
             }
         }
+        if (wave < FB / 64) {
+            // per-quadrant record bitmaps: wave q later walks only the set bits (scalar ctz loop)
+            const uint32_t pmv = tid < nb ? cur.pm : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t b = ballot64((pmv >> q) & 1u);
+                if (lane == 0) s_bits[q][wave] = b;
+            }
+        }
         if (tid < FB && b0 + FB + tid < ns_total) cur = rec[b0 + FB + tid];
         if constexpr (VEC_STAGE) {
             // ---- B: features (ids straight from the records: thread q reads record q / F4)
@@ -119,22 +146,40 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
         }
         __syncthreads();
 
-        // ---- C: blend
+        // ---- C: blend.  The wave walks the set bits of its quadrant's bitmap; the body is branch-free around the
+        // accumulate so that the 32-register MFMA accumulator tile stays pinned (no phi copies).
         if (ballot64(!done) != 0) {
             walked = b0 + nb;
-            float2 nxy = s_xy[0];
-            float4 nco = s_co[0];
-            uint32_t npm = s_pm[0];
-            for (int k = 0; k < nb; k++) {
+            // compact this quadrant's record indices (wave-local: bitmap -> index list via mbcnt)
+            int cnt = 0;
+#pragma unroll
+            for (int h = 0; h < FB / 64; h++) {
+                const uint64_t b = s_bits[wave][h];
+                const bool set = (b >> lane) & 1ull;
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                if (set) s_list[wave][cnt + below] = (uint8_t)(64 * h + lane);
+                cnt += __builtin_popcountll(b);
+            }
+            cnt = __builtin_amdgcn_readfirstlane(cnt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            int j = 0;
+            int k = cnt > 0 ? (int)__builtin_amdgcn_readfirstlane((uint32_t)s_list[wave][0]) : -1;
+            float2 nxy = s_xy[k < 0 ? 0 : k];
+            float4 nco = s_co[k < 0 ? 0 : k];
+            uint32_t npm = s_pm[k < 0 ? 0 : k];
+            bool finished = false;
+            uint32_t last_pm = 0;
+            int last_k = 0;
+            while (k >= 0 && !finished) {
                 const float2 cxy = nxy;
                 const float4 cco = nco;
                 const uint32_t pm = __builtin_amdgcn_readfirstlane(npm);
-                const int kn = k + 1 < nb ? k + 1 : k;  // prefetch the next record
-                nxy = s_xy[kn];
-                nco = s_co[kn];
-                npm = s_pm[kn];
-                if (!((pm >> wave) & 1u)) continue;  // culled for this quadrant
-                if (ablate & 2) continue;
+                j++;
+                const int kn = j < cnt ? (int)__builtin_amdgcn_readfirstlane((uint32_t)s_list[wave][j]) : -1;
+                const int kp = kn < 0 ? k : kn;  // prefetch the next record of this quadrant
+                nxy = s_xy[kp];
+                nco = s_co[kp];
+                npm = s_pm[kp];
                 const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
                 const float power = -0.5f * (cco.x * dx * dx + cco.z * dy * dy) - cco.y * dx * dy;
                 const float alpha = fminf(0.99f, cco.w * __expf(power));
@@ -143,22 +188,38 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                 const bool stop = ok && test_T < 0.0001f;
                 done = done || stop;
                 const bool blend = ok && !stop;
-                if (ballot64(blend) != 0) {
-                    const float w = blend ? alpha * T : 0.f;
-                    if (!(ablate & 1))
+                const float w = blend ? alpha * T : 0.f;
+                if constexpr (USE_MFMA) {
 #pragma unroll
-                    for (int ch = 0; ch < CE; ch++) acc[ch] = fmaf(s_feat[k * ROW + ch], w, acc[ch]);
-                    T = blend ? test_T : T;
-                    last_contributor = blend ? (pm >> 4) + 1u : last_contributor;
+                    for (int a = 0; a < NACC; a++) {
+                        // Inline asm with a tied "+v" accumulator: with the builtin hipcc shuttles all 32 accumulator
+                        // registers VGPR<->AGPR (or v_mov's them) around every MFMA that sits behind a branch.
+                        // Hazards handled here (cdna_hip_programming.md 5.7): s_nop 1 covers a just-written VGPR
+                        // operand -> MFMA; an accumulate chain on the same registers needs 0 states; the epilogue
+                        // waits before its VALU reads the tile.  Lanes that do not blend contribute w = 0.
+                        const float fb = s_feat[k * ROW + 32 * a + (lane & 31)];
+                        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x1_2b_f32 %0, %1, %2, %0" : "+v"(accv[a]) : "v"(w), "v"(fb));
+                    }
+                } else {
+                    if (ballot64(blend) != 0) {
+#pragma unroll
+                        for (int ch = 0; ch < CE; ch++) acc[ch] = fmaf(s_feat[k * ROW + ch], w, acc[ch]);
+                    }
                 }
-                if (ballot64(!done) == 0) {  // this wave is finished
-                    consumed = (int)(pm >> 4) + 1;
-                    walked = b0 + k + 1;
-                    break;
-                }
+                T = blend ? test_T : T;
+                last_contributor = blend ? (pm >> 4) + 1u : last_contributor;
+                finished = ballot64(!done) == 0;  // this wave is finished
+                last_pm = pm;
+                last_k = k;
+                k = kn;
+            }
+            if (finished) {
+                consumed = (int)(last_pm >> 4) + 1;
+                walked = b0 + last_k + 1;
             }
         }
     }
+
     if (lane == 0) {
         atomicMax(&s_consumed, consumed);
         atomicMax(&s_walked, walked);
@@ -168,10 +229,45 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
         tile_consumed[tile] = (uint32_t)s_consumed;
         tile_nsurv[tile] = (uint32_t)s_walked;
     }
+    const size_t HW = (size_t)H * W;
     if (inside) {
         final_T[pix_id] = T;
         n_contrib[pix_id] = last_contributor;
-        const size_t HW = (size_t)H * W;
+    }
+    if constexpr (USE_MFMA) {
+        // accumulator tile: lane l holds channel (l & 31) of 32 pixels: register r <-> pixel lane index
+        // L(r, l) = 32*(r>>4) + (r&3) + 8*((r&15)>>2) + 4*(l>>5)   (probed on gfx950, tools/mfma_probe.hip).
+        // Transpose through LDS, 8 channels at a time per wave ([8][65] floats, reusing the feature buffer
+        // -- every wave is past the last barrier-protected use of it), then store pixel-major.
+        static_assert(FB * ROW >= 4 * 8 * 65, "feature buffer too small for the epilogue transpose");
+        float* tp = s_feat + wave * 8 * 65;
+        // 16-pass MFMA result -> VALU reader needs 18 wait states (the barrier above makes this moot in
+        // practice; kept so correctness never depends on timing)
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < NACC; a++) {
+#pragma unroll
+            for (int part = 0; part < 4; part++) {
+                const int chl = lane & 31;  // channel within the 32-tile
+                if ((chl >> 3) == part) {
+#pragma unroll
+                    for (int r = 0; r < 32; r++) {
+                        const int L = 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * (lane >> 5);
+                        tp[(chl & 7) * 65 + L] = accv[a][r];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (inside) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int ch = 32 * a + 8 * part + c;
+                        out_color[ch * HW + pix_id] = tp[c * 65 + lane] + T * bg_color[ch];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        }
+    } else if (inside) {
 #pragma unroll
         for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix_id] = acc[ch] + T * bg_color[ch];
         if constexpr (EXTRA >= 1) out_mask[pix_id] = acc[C];
