@@ -1,0 +1,339 @@
+// blend_bwd_mfma.h -- per-tile back-to-front gradient pass for C = 32 feature channels on the matrix pipe.
+//
+// Same mathematics as blend_bwd.h (which restates renderCUDA<C> backward, CF/cuda_rasterizer/backward.cu:399-559,
+// and remains the path for C = 3 / 64 and the mask variants); same tolerance-checked results.  What changes is
+// where the work runs.  Per valid (wave, Gaussian) pair the VALU version spends ~250 instructions and ~250 LDS
+// cycles, almost all of them in three contractions:
+//     S[g][p]   = sum_ch  f[g][ch]  * dL[p][ch]        (feeds dL/dalpha through the scalar recurrence)
+//     dF[g][ch] = sum_p   w[g][p]   * dL[p][ch]        (the colour/feature gradient)
+//     M[g][j]   = sum_p   u[g][p]   * Phi[p][j]        (six pixel moments 1, x, y, x^2, xy, y^2 of
+//                                                        u = dL/dG * G, from which dL/dmean2D, dL/dconic and
+//                                                        dL/dopacity of the Gaussian follow in closed form)
+// A wave (8x8 pixels) therefore processes its records in chunks of 16 rows:
+//   1. S for 16 rows x 64 pixels: 32 v_mfma_f32_16x16x4_f32 (A = feature rows read from LDS as MFMA operands,
+//      B = dL held in registers), then a transpose through LDS so that lane = pixel again;
+//   2. the short scalar recurrences per pixel (T, R, dL/dalpha: ~35 VALU per row), which leave w and u of the
+//      16 rows in LDS, transposed;
+//   3. dF (32 MFMA) and M (16 MFMA) with A = w / u rows from LDS and B = dL (registers) / Phi (generated on the fly);
+//   4. per row ONE 128-byte line of float atomics for dF and ONE 32-byte packed record {mean2D.xy, conic.xyw,
+//      opacity} -- rows without any contributing pixel are skipped.
+// f32 MFMA is an exact fmaf chain (no reduced precision).  Moments are taken about the quadrant centre, so
+// |coordinate| <= 3.5 and recentring to the Gaussian mean is benign (all terms of a sum share their sign pattern
+// with the direct evaluation).
+#pragma once
+
+#include "blend_fwd.h"
+#include "common.h"
+
+namespace mirast {
+
+constexpr int RB2 = 128;   // blend-list records per batch
+constexpr int FROW = 36;   // padded feature row (floats): conflict-free 16-lane b128 operand reads
+constexpr int WROW = 68;   // padded w/u row (floats)
+constexpr int CHK = 16;    // rows per MFMA chunk
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
+    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
+    int W, int H, const float* __restrict__ bg_color, const float* __restrict__ colors,
+    const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    float* __restrict__ gpack /*[P,8] packed field gradients*/, float* __restrict__ dL_dcolors)
+{
+    constexpr int C = 32;
+    __shared__ float2 s_xy[RB2];
+    __shared__ float4 s_co[RB2];
+    __shared__ uint32_t s_id[RB2];
+    __shared__ uint32_t s_pm[RB2];
+    __shared__ float4 s_feat4[RB2 * FROW / 4];
+    __shared__ uint64_t s_bits[4][RB2 / 64];
+    __shared__ uint8_t s_list[4][RB2];
+    __shared__ float4 s_wa4[4][CHK * WROW / 4];
+    __shared__ float4 s_ua4[4][CHK * WROW / 4];
+    __shared__ float4 s_mom4[4][CHK * 8 / 4];
+    __shared__ int s_maxc;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const uint32_t horizontal_blocks = (W + TILE_X - 1) / TILE_X;
+    const uint32_t tile = blockIdx.y * horizontal_blocks + blockIdx.x;
+    const uint32_t qx0 = blockIdx.x * TILE_X + (wave & 1) * 8, qy0 = blockIdx.y * TILE_Y + (wave >> 1) * 8;
+    const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const uint32_t pix_id = W * py + px;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const size_t HW = (size_t)H * W;
+
+    const uint2 range = ranges[tile];
+    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
+    if (tid == 0) s_maxc = 0;
+    __syncthreads();
+    int wave_Lt = last_contributor;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wave_Lt = max(wave_Lt, __shfl_xor(wave_Lt, o, 64));
+    if (lane == 0) atomicMax(&s_maxc, wave_Lt);
+    __syncthreads();
+    if (s_maxc == 0) return;
+    const int NS = (int)tile_nsurv[tile];
+    const BlendRec* rec = blend_rec + range.x;
+
+    const float T_final = inside ? final_Ts[pix_id] : 0;
+    float T = T_final;
+
+    // ---- gradient image of this quadrant in the two MFMA operand layouts
+    const int n16 = lane & 15, kq = lane >> 4;
+    auto pix_of = [&](int i, bool& in) -> size_t {  // quadrant-local pixel index (== lane index of its owner)
+        const uint32_t x = qx0 + (i & 7), y = qy0 + (i >> 3);
+        in = x < (uint32_t)W && y < (uint32_t)H;
+        return in ? (size_t)W * y + x : 0;
+    };
+    // B of the S contraction: dLB[pb][s] = dL[pixel 16*pb + n16][channel 8*kq + s]
+    float dLB[4][8];
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) {
+        bool in;
+        const size_t p = pix_of(16 * pb + n16, in);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const float v = dL_dpixels[(size_t)(8 * kq + s) * HW + p];
+            dLB[pb][s] = in ? v : 0.f;
+        }
+    }
+    // B of the dF contraction: dLT[nb][s] = dL[pixel 16*kq + s][channel 16*nb + n16]
+    float dLT[2][16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        bool in;
+        const size_t p = pix_of(16 * kq + s, in);
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+            const float v = dL_dpixels[(size_t)(16 * nb + n16) * HW + p];
+            dLT[nb][s] = in ? v : 0.f;
+        }
+    }
+    // bg . dL of this lane's own pixel (backward.cu:533-535)
+    float bg_dot_dpixel = 0.f;
+    {
+        const size_t pix_safe = inside ? pix_id : 0;
+#pragma unroll 8
+        for (int ch = 0; ch < C; ch++) {
+            const float v = dL_dpixels[(size_t)ch * HW + pix_safe];
+            bg_dot_dpixel += bg_color[ch] * (inside ? v : 0.f);
+        }
+    }
+
+    float last_alpha = 0.f, S_last = 0.f, Rrec = 0.f;
+    const float ddelx_dx = 0.5 * W;  // backward.cu:460-461
+    const float ddely_dy = 0.5 * H;
+    const float cxq = (float)qx0 + 3.5f, cyq = (float)qy0 + 3.5f;  // moment origin: quadrant centre
+    float* my_wa = reinterpret_cast<float*>(s_wa4[wave]);
+    float* my_ua = reinterpret_cast<float*>(s_ua4[wave]);
+    float* my_mom = reinterpret_cast<float*>(s_mom4[wave]);
+
+    BlendRec cur;
+    if (tid < RB2 && tid < NS) cur = rec[NS - 1 - tid];
+
+    for (int b0 = 0; b0 < NS; b0 += RB2) {
+        const int nr = min(RB2, NS - b0);  // records in this batch, walked back to front
+        __syncthreads();                   // LDS reuse
+        // ---- A: records -> LDS; next batch's record -> registers; quadrant bitmaps
+        if (tid < nr) {
+            s_xy[tid] = cur.xy;
+            s_co[tid] = cur.co;
+            s_id[tid] = cur.id;
+            s_pm[tid] = cur.pm;
+        }
+        if (wave < RB2 / 64) {
+            const uint32_t pmv = tid < nr ? cur.pm : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t b = ballot64((pmv >> q) & 1u);
+                if (lane == 0) s_bits[q][wave] = b;
+            }
+        }
+        if (tid < RB2 && b0 + RB2 + tid < NS) cur = rec[NS - 1 - (b0 + RB2 + tid)];
+        // ---- B: feature rows (padded to FROW floats)
+        {
+#pragma unroll
+            for (int k = 0; k < RB2 * 8 / BATCH; k++) {
+                const int q = tid + BATCH * k;
+                const int g = q >> 3, part = q & 7;
+                if (g < nr)
+                    s_feat4[g * (FROW / 4) + part] = reinterpret_cast<const float4*>(colors + (size_t)rec[NS - 1 - (b0 + g)].id * C)[part];
+            }
+        }
+        __syncthreads();
+
+        // ---- this quadrant's rows, back to front, restricted to positions below the quadrant's max n_contrib
+        int cnt = 0;
+#pragma unroll
+        for (int h = 0; h < RB2 / 64; h++) {
+            const int ridx = 64 * h + lane;
+            const bool cand = ((s_bits[wave][h] >> lane) & 1ull) && ridx < nr && (int)(s_pm[ridx < nr ? ridx : 0] >> 4) < wave_Lt;
+            const uint64_t b = ballot64(cand);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (cand) s_list[wave][cnt + below] = (uint8_t)ridx;
+            cnt += __builtin_popcountll(b);
+        }
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        for (int j0 = 0; j0 < cnt; j0 += CHK) {
+            const int nrow = min(CHK, cnt - j0);
+            // ---- 1. S = F . dL^T  (16 rows x 64 pixels, K = 32 channels)
+            v4f sacc[4];
+            {
+                const int jr = j0 + n16;  // this lane's operand row
+                const int km = s_list[wave][jr < cnt ? jr : j0];
+                const float4 fa0 = s_feat4[km * (FROW / 4) + 2 * kq];
+                const float4 fa1 = s_feat4[km * (FROW / 4) + 2 * kq + 1];
+                const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
+#pragma unroll
+                for (int pb = 0; pb < 4; pb++) sacc[pb] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+#pragma unroll
+                    for (int pb = 0; pb < 4; pb++)
+                        sacc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], dLB[pb][s], sacc[pb], 0, 0, 0);
+            }
+            // Transpose to lane = pixel through LDS (the w-row buffer is free until step 2 writes it): lane 16g+p
+            // holds row 4g+r of pixel 16pb+p in sacc[pb][r]; both the writes and the row reads are conflict-free
+            // (row stride 68 floats).  (A register-only v_permlane16/32_swap transpose is 16 instructions, but
+            // hipcc 7.2 miscompiles that builtin sequence -- tools/s_probe.hip -- so LDS it is.)
+            float Srow[16];
+            {
+#pragma unroll
+                for (int pb = 0; pb < 4; pb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) my_wa[(4 * kq + r) * WROW + 16 * pb + n16] = sacc[pb][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                for (int m = 0; m < 16; m++) Srow[m] = my_wa[m * WROW + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+
+            // ---- 2. scalar recurrences (lane = pixel), back to front
+            uint32_t rowmask = 0;
+#pragma unroll
+            for (int rr = 0; rr < CHK; rr++) {
+                float w = 0.f, u = 0.f;
+                if (rr < nrow) {
+                    const int k = __builtin_amdgcn_readfirstlane((int)s_list[wave][j0 + rr]);
+                    const float2 cxy = s_xy[k];
+                    const float4 cco = s_co[k];
+                    const int pos = (int)(s_pm[k] >> 4);
+                    const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
+                    const float power = -0.5f * (cco.x * dx * dx + cco.z * dy * dy) - cco.y * dx * dy;
+                    const float G = __expf(power);
+                    const float alpha = fminf(0.99f, cco.w * G);
+                    const bool valid = (pos < last_contributor) && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                    const float one_m_alpha_inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = valid ? T * one_m_alpha_inv : T;
+                    w = valid ? alpha * T : 0.f;  // dchannel_dcolor
+                    const float S = Srow[rr];
+                    Rrec = valid ? (last_alpha * S_last + (1.f - last_alpha) * Rrec) : Rrec;
+                    float dL_dalpha = (S - Rrec) * T;
+                    S_last = valid ? S : S_last;
+                    last_alpha = valid ? alpha : last_alpha;
+                    dL_dalpha += (-T_final * one_m_alpha_inv) * bg_dot_dpixel;
+                    u = valid ? cco.w * dL_dalpha * G : 0.f;  // dL/dG * G
+                    rowmask |= (ballot64(valid) != 0 ? 1u : 0u) << rr;
+                }
+                my_wa[rr * WROW + lane] = w;
+                my_ua[rr * WROW + lane] = u;
+            }
+            rowmask = __builtin_amdgcn_readfirstlane(rowmask);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (rowmask == 0) continue;
+
+            // ---- 3. dF = W^T . dL  and  M = U^T . Phi   (A rows from LDS, lane (m = n16, kq) reads pixels 16kq..16kq+15)
+            v4f facc[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
+            v4f macc = (v4f){0.f, 0.f, 0.f, 0.f};
+            {
+                const float4* wrow = reinterpret_cast<const float4*>(my_wa + n16 * WROW + 16 * kq);
+                const float4* urow = reinterpret_cast<const float4*>(my_ua + n16 * WROW + 16 * kq);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const float4 wv = wrow[s4];
+                    const float4 uv = urow[s4];
+                    const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
+                    const float ua[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int s = 4 * s4 + t;
+                        facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[0][s], facc[0], 0, 0, 0);
+                        facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[1][s], facc[1], 0, 0, 0);
+                        // Phi[pixel 16kq+s][j = n16]: monomials about the quadrant centre
+                        const int i = 16 * kq + s;
+                        const float xx = (float)(i & 7) - 3.5f, yy = (float)(i >> 3) - 3.5f;
+                        float phi = 0.f;
+                        phi = n16 == 0 ? 1.f : phi;
+                        phi = n16 == 1 ? xx : phi;
+                        phi = n16 == 2 ? yy : phi;
+                        phi = n16 == 3 ? xx * xx : phi;
+                        phi = n16 == 4 ? xx * yy : phi;
+                        phi = n16 == 5 ? yy * yy : phi;
+                        macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
+                    }
+                }
+            }
+            // ---- 4. outputs.  Result layout: lane l holds column n16 of rows 4*kq + r.
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * kq + r;
+                const bool act = (rowmask >> row) & 1u;
+                const int krow = s_list[wave][j0 + (row < nrow ? row : 0)];
+                const uint32_t gid = s_id[krow];
+                if (act) {
+                    atomicAdd(&dL_dcolors[(size_t)gid * C + n16], facc[0][r]);
+                    atomicAdd(&dL_dcolors[(size_t)gid * C + 16 + n16], facc[1][r]);
+                }
+                if (n16 < 8) my_mom[row * 8 + n16] = macc[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // moments -> fields: lane = row (16 lanes) rewrites its my_mom row in place, then the wave adds the rows
+            // to the packed per-Gaussian records: lane -> (row = l / 8 (+8), field = l % 8), 24 contiguous bytes per row
+            {
+                const int row = lane & 15;
+                const bool act = lane < 16 && ((rowmask >> row) & 1u);
+                if (act) {
+                    const int krow = s_list[wave][j0 + row];
+                    const float4 m0 = reinterpret_cast<const float4*>(my_mom + row * 8)[0];
+                    const float4 m1 = reinterpret_cast<const float4*>(my_mom + row * 8)[1];
+                    const float M0 = m0.x, M1 = m0.y, M2 = m0.z, M3 = m0.w, M4 = m1.x, M5 = m1.y;
+                    const float2 gxy = s_xy[krow];
+                    const float4 gco = s_co[krow];
+                    const float gx = gxy.x - cxq, gy = gxy.y - cyq;
+                    // dx = gx - x', dy = gy - y'
+                    const float Sdx = gx * M0 - M1;
+                    const float Sdy = gy * M0 - M2;
+                    const float Sdxx = gx * gx * M0 - 2.f * gx * M1 + M3;
+                    const float Sdxy = gx * gy * M0 - gx * M2 - gy * M1 + M4;
+                    const float Sdyy = gy * gy * M0 - 2.f * gy * M2 + M5;
+                    float4 o0, o1;
+                    o0.x = -ddelx_dx * (gco.x * Sdx + gco.y * Sdy);  // dL_dmean2D.x
+                    o0.y = -ddely_dy * (gco.z * Sdy + gco.y * Sdx);  // dL_dmean2D.y
+                    o0.z = -0.5f * Sdxx;                             // dL_dconic.x
+                    o0.w = -0.5f * Sdxy;                             // dL_dconic.y
+                    o1.x = -0.5f * Sdyy;                             // dL_dconic.w
+                    o1.y = M0 * __builtin_amdgcn_rcpf(gco.w);        // dL_dopacity = sum G dL_dalpha
+                    o1.z = 0.f;
+                    o1.w = 0.f;
+                    reinterpret_cast<float4*>(my_mom + row * 8)[0] = o0;
+                    reinterpret_cast<float4*>(my_mom + row * 8)[1] = o1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int row2 = 8 * it + (lane >> 3), f = lane & 7;
+                    if (((rowmask >> row2) & 1u) && f < 6) {
+                        const int krow = s_list[wave][j0 + row2];
+                        atomicAdd(&gpack[(size_t)s_id[krow] * 8 + f], my_mom[row2 * 8 + f]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mirast

@@ -13,6 +13,7 @@
 
 #include "binning.h"
 #include "blend_bwd.h"
+#include "blend_bwd_mfma.h"
 #include "blend_fwd.h"
 #include "common.h"
 #include "geometry.h"
@@ -502,6 +503,10 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float), stream));
         if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor);
         else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
+        else if (channels == 32 && !(g_ablate & 1024))
+            hipLaunchKernelGGL(blend_bwd32_mfma_kernel, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+                               bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib,
+                               dL_dpix, geom.bwd_pack, dL_dcolor);
         else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
         else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
     }
