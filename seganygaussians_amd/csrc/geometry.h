@@ -114,8 +114,8 @@ __device__ __forceinline__ float3 computeColorFromSH(int idx, int deg, int max_c
 // `culled_prefiltered` is incremented when prefiltered is set and a point is culled (the reference
 // printf+__trap()s the whole context there; we report an error instead).
 // gfx950 additions (binning.h): writes the 32-bit depth sort key (0xFFFFFFFF for culled Gaussians) and the
-// identity index array for the depth sort, and histograms the tile overlaps into tile_count[] with the
-// wave-balanced rect walk.
+// identity index array for the depth sort, and records the tile rect in the 2-D difference grid that
+// tile_scan_kernel integrates into per-tile counts.
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -123,11 +123,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int* __restrict__ radii, float2* __restrict__ points_xy_image, float* __restrict__ depths,
     float* __restrict__ cov3Ds, float* __restrict__ rgb, float4* __restrict__ conic_opacity,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ idx_iota,
-    uint32_t* __restrict__ tile_count, int prefiltered, int* __restrict__ culled_prefiltered)
+    int* __restrict__ diff_grid, int prefiltered, int* __restrict__ culled_prefiltered)
 {
-    __shared__ uint32_t s_prefix[4][64], s_rx[4][64], s_ry[4][64];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int my_radii = 0;
     uint32_t my_tiles = 0;
     uint32_t my_key = 0xFFFFFFFFu;
@@ -195,11 +193,14 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         depth_key[idx] = my_key;
         idx_iota[idx] = (uint32_t)idx;
     }
-    const uint32_t count = (rect_max.x - rect_min.x) * (rect_max.y - rect_min.y);
-    if (ballot64(count != 0) == 0) return;
-    RectWork rw{s_prefix[wave], s_rx[wave], s_ry[wave]};
-    for_each_tile_balanced(rw, lane, rect_min, rect_max, count, vp.grid_x,
-                           [&](uint32_t, uint32_t tile) { atomicAdd(&tile_count[tile], 1u); });
+    // tile-overlap histogram as a 2-D difference grid ((grid_y+1) x (grid_x+1), one cell per 128-B line)
+    if ((rect_max.x - rect_min.x) * (rect_max.y - rect_min.y) != 0) {
+        const int gw = (int)vp.grid_x + 1;
+        atomicAdd(&diff_grid[(size_t)(rect_min.y * gw + rect_min.x) * GRID_STRIDE], 1);
+        atomicAdd(&diff_grid[(size_t)(rect_min.y * gw + rect_max.x) * GRID_STRIDE], -1);
+        atomicAdd(&diff_grid[(size_t)(rect_max.y * gw + rect_min.x) * GRID_STRIDE], -1);
+        atomicAdd(&diff_grid[(size_t)(rect_max.y * gw + rect_max.x) * GRID_STRIDE], 1);
+    }
 }
 
 // CF/cuda_rasterizer/rasterizer_impl.cu:54-66

@@ -237,14 +237,17 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     int* cull_counter = (int*)geom.sort_temp;
     if (prefiltered) HIP_TRY(hipMemsetAsync(cull_counter, 0, sizeof(int), stream));
     const int ntiles = (int)(vp.grid_x * vp.grid_y);
+    const size_t grid_cells = (size_t)(vp.grid_x + 1) * (vp.grid_y + 1);
+    if (grid_cells > (size_t)SCAN_GRID_MAX)
+        return fail(MI_RAST_ERR_INVALID, "image too large: more than 36K tile-grid cells (about 4800 x 1900 px at 16-px tiles)");
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
-        HIP_TRY(hipMemsetAsync(img.tile_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(img.tile_count, 0, grid_cells * GRID_STRIDE * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(img.blend_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
-                           geom.depth_key, geom.idx_iota, img.tile_count, prefiltered, cull_counter);
+                           geom.depth_key, geom.idx_iota, (int*)img.tile_count, prefiltered, cull_counter);
     }
     STAGE_CHECK("preprocess");
     if (prefiltered) {
@@ -258,8 +261,16 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         // tile scan first: it only needs tile_count, and its result (R) is what the host waits for; the depth
         // sort of the Gaussians is queued behind it and overlaps the host round trip + buffer allocation.
         StageTimer t(stream, MI_STAGE_TILE_SCAN);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, ntiles, img.tile_count, img.ranges,
-                           img.tile_cursor, img.num_rendered);
+        if (grid_cells * sizeof(int) > 48 * 1024) {
+            static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
+            if (!attr_set) {
+                HIP_TRY(hipFuncSetAttribute((const void*)tile_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            SCAN_GRID_MAX * (int)sizeof(int)));
+                attr_set = true;
+            }
+        }
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), grid_cells * sizeof(int), stream, (int)vp.grid_x,
+                           (int)vp.grid_y, (const int*)img.tile_count, img.ranges, img.tile_cursor, img.num_rendered);
     }
     STAGE_CHECK("tile scan");
     if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host word / event");
@@ -382,7 +393,8 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     off[MI_IMG_N_CONTRIB] = c.take(n * sizeof(uint32_t));
     off[MI_IMG_RANGES] = c.take((tiles ? tiles : 1) * sizeof(uint2));
     off[MI_IMG_TILE_CONSUMED] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
-    off[MI_IMG_TILE_COUNT] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
+    // tile_count holds the (gy+1) x (gx+1) difference grid of the tile-overlap histogram, one cell per 128-B line
+    off[MI_IMG_TILE_COUNT] = c.take((size_t)((width + TILE_X - 1) / TILE_X + 1) * ((height + TILE_Y - 1) / TILE_Y + 1) * GRID_STRIDE * sizeof(int));
     off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_NUM_RENDERED] = c.take(16);
     off[MI_IMG_BLEND_COUNT] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
