@@ -81,6 +81,7 @@ def main():
     from seganygaussians_amd import _lib, install_dropin, scenes
     install_dropin()
     from diff_gaussian_rasterization_contrastive_f import GaussianRasterizationSettings
+    from seganygaussians_amd.dist import allreduce_grads
     from seganygaussians_amd.rasterizer import make_rasterizer
 
     cfg = scenes.CONFIGS[args.config]
@@ -115,8 +116,8 @@ def main():
                                   scales=scales, rotations=rots, cov3D_precomp=None)
         torch.autograd.backward(color, grad_tensors=dL)
         if dist is not None:
-            # config 4: sum the per-Gaussian feature gradients of the N views over RCCL/xGMI
-            dist.all_reduce(feats.grad, op=dist.ReduceOp.SUM)
+            # config 4: sum the per-Gaussian feature gradients of the N views over RCCL/xGMI (one flat 128-MB bucket)
+            allreduce_grads([feats.grad])
         state["radii"] = radii
 
     def barrier():

@@ -1,0 +1,88 @@
+"""View-sharded multi-GPU step (BASELINE config 4).
+
+The rasterizer hot path shards over VIEWS: every rank holds the full (replicated) Gaussian parameters,
+renders and back-propagates its own camera(s), and the only exchange is the SUM of the per-Gaussian
+gradients before the optimizer step.  One process per GPU, `torch.distributed` ("nccl" == RCCL over xGMI on
+ROCm; "gloo" on CPU for tests).  The reference itself has no distributed layer (single process, cuda:0);
+this is the new batch semantic "gradient = sum over the N views of an iteration".
+
+What is exchanged: in SAGA's contrastive training only `_point_features` is optimised
+(scene/gaussian_model_ff.py:154-162), so the message is dL/d(features): P x C fp32 (128 MB at 1M x 32).
+`allreduce_grads` sends each tensor as ONE flat bucket -- on MI355X's point-to-point xGMI mesh large
+messages let RCCL drive all 7 links (ring algorithms are per-link bound), so a few big collectives beat many
+small ones.  Passing several tensors coalesces them into a single flat buffer first.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def views_for_rank(num_views: int, rank: int, world_size: int) -> List[int]:
+    """Round-robin view ownership: rank r renders views r, r + world, r + 2*world, ...."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    return list(range(rank, num_views, world_size))
+
+
+def allreduce_grads(tensors: Sequence[Optional[torch.Tensor]], group=None, average: bool = False) -> None:
+    """In-place SUM (or mean) all-reduce of gradient tensors across ranks, coalesced into one flat bucket per
+    dtype/device.  `None` entries are skipped.  No-op when torch.distributed is not initialised (1 GPU)."""
+    ts = [t for t in tensors if t is not None]
+    if not ts or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    if len(ts) == 1 and ts[0].is_contiguous():
+        dist.all_reduce(ts[0], op=dist.ReduceOp.SUM, group=group)
+        if average:
+            ts[0].div_(world)
+        return
+    buckets = {}
+    for t in ts:
+        buckets.setdefault((t.dtype, t.device), []).append(t)
+    for (_dt, _dev), group_ts in buckets.items():
+        flat = torch.cat([t.reshape(-1) for t in group_ts])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat.div_(world)
+        off = 0
+        for t in group_ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+class ViewShardedStep:
+    """One training iteration over `num_views` views sharded across the ranks.
+
+    `render_backward(view_index)` must render that view with the drop-in rasterizer and call `.backward()`
+    (gradients accumulate in the `.grad` of `params`); this class zeroes the grads, runs the local views,
+    and sums the gradients over ranks.  The optimizer step stays with the caller (it is identical on every
+    rank because parameters and summed gradients are)."""
+
+    def __init__(self, params: Iterable[torch.Tensor], group=None, average: bool = False):
+        self.params = [p for p in params]
+        self.group = group
+        self.average = average
+
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def __call__(self, num_views: int, render_backward) -> List[int]:
+        for p in self.params:
+            p.grad = None
+        mine = views_for_rank(num_views, self.rank, self.world_size)
+        for v in mine:
+            render_backward(v)
+        for p in self.params:
+            if p.grad is None:  # a rank without views (num_views < world) still joins the collective
+                p.grad = torch.zeros_like(p)
+        allreduce_grads([p.grad for p in self.params], group=self.group, average=self.average)
+        return mine

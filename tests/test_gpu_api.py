@@ -1,0 +1,111 @@
+"""GPU tests through the drop-in Python packages (the reference's extension API): autograd plumbing, gradient
+tuple order (CF/diff_gaussian_rasterization_contrastive_f/__init__.py:142-152), the depth package's extra
+mask argument / forward_mask, markVisible, and the debug snapshot path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import seganygaussians_amd
+from oracle import saga_oracle as so
+from seganygaussians_amd import scenes
+from tests import helpers as hp
+
+seganygaussians_amd.install_dropin()
+pytestmark = pytest.mark.gpu
+
+
+def _settings(mod, inp, dev, debug=False):
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    return mod.GaussianRasterizationSettings(
+        image_height=inp.image_height, image_width=inp.image_width, tanfovx=inp.tanfovx, tanfovy=inp.tanfovy,
+        bg=t(inp.bg), scale_modifier=inp.scale_modifier, viewmatrix=t(inp.viewmatrix), projmatrix=t(inp.projmatrix),
+        sh_degree=inp.sh_degree, campos=t(inp.campos), prefiltered=False, debug=debug)
+
+
+def _leaf(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev).requires_grad_(True)
+
+
+@pytest.mark.parametrize("pkg,C", [("diff_gaussian_rasterization", 3), ("diff_gaussian_rasterization_contrastive_f", 32)])
+def test_autograd_through_dropin(pkg, C):
+    mod = __import__(pkg)
+    dev = torch.device("cuda:0")
+    inp = hp.make_inputs(6000, 208, 144, C, seed=31, bg="random", camera="orbit")
+    means3D, feats = _leaf(inp.means3D, dev), _leaf(inp.colors_precomp, dev)
+    opac, scales, rots = _leaf(inp.opacities, dev), _leaf(inp.scales, dev), _leaf(inp.rotations, dev)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    rast = mod.GaussianRasterizer(raster_settings=_settings(mod, inp, dev))
+    color, radii = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=feats, opacities=opac,
+                        scales=scales, rotations=rots, cov3D_precomp=None)
+    assert color.shape == (C, 144, 208) and radii.dtype == torch.int32 and not radii.requires_grad
+    dL = scenes.make_grad_image(C, 144, 208, seed=2)
+    (color * torch.as_tensor(dL).to(dev)).sum().backward()
+    fwd = so.forward(inp)
+    bwd = so.backward(inp, fwd, dL)
+    np.testing.assert_array_equal(radii.cpu().numpy(), fwd.radii)
+    hp.assert_close("color", color.detach().cpu().numpy(), fwd.color, flip_frac=hp.FLIP_FRAC)
+    for name, leaf, want in [("means3D", means3D, bwd.dL_dmeans3D), ("means2D", means2D, bwd.dL_dmeans2D),
+                             ("colors_precomp", feats, bwd.dL_dcolors), ("opacities", opac, bwd.dL_dopacity),
+                             ("scales", scales, bwd.dL_dscales), ("rotations", rots, bwd.dL_drotations)]:
+        hp.assert_close(name, leaf.grad.cpu().numpy(), np.asarray(want).reshape(leaf.shape), flip_frac=hp.GRAD_FLIP_FRAC)
+    vis = rast.markVisible(means3D.detach())
+    np.testing.assert_array_equal(vis.cpu().numpy(), so.mark_visible(inp.means3D, inp.viewmatrix, inp.projmatrix))
+    # no_grad forward (render.py path)
+    with torch.no_grad():
+        c2, _ = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=feats, opacities=opac, scales=scales,
+                     rotations=rots, cov3D_precomp=None)
+    assert torch.equal(c2, color.detach())
+
+
+def test_depth_package_and_forward_mask():
+    import diff_gaussian_rasterization_depth as mod
+    dev = torch.device("cuda:0")
+    inp = hp.make_inputs(5000, 176, 128, 3, seed=32, with_shs=True, sh_degree=2, use_mask=True, bg="random")
+    means3D, shs = _leaf(inp.means3D, dev), _leaf(inp.shs, dev)
+    opac, scales, rots, mask = _leaf(inp.opacities, dev), _leaf(inp.scales, dev), _leaf(inp.rotations, dev), _leaf(inp.mask, dev)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    rast = mod.GaussianRasterizer(raster_settings=_settings(mod, inp, dev))
+    color, omask, depth, radii = rast(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opac,
+                                      mask=mask, scales=scales, rotations=rots, cov3D_precomp=None)
+    assert omask.shape == (1, 128, 176) and depth.shape == (1, 128, 176)
+    dL = scenes.make_grad_image(3, 128, 176, seed=3)
+    dLm = (np.random.default_rng(4).normal(0, 1, (1, 128, 176)) / (128 * 176)).astype(np.float32)
+    ((color * torch.as_tensor(dL).to(dev)).sum() + (omask * torch.as_tensor(dLm).to(dev)).sum()).backward()
+    fwd = so.forward(inp)
+    bwd = so.backward(inp, fwd, dL, dLm[0])
+    hp.assert_close("color", color.detach().cpu().numpy(), fwd.color, flip_frac=hp.FLIP_FRAC)
+    hp.assert_close("mask", omask.detach().cpu().numpy(), fwd.mask, flip_frac=hp.FLIP_FRAC)
+    hp.assert_close("depth", depth.detach().cpu().numpy(), fwd.depth, flip_frac=hp.FLIP_FRAC)
+    for name, leaf, want in [("means3D", means3D, bwd.dL_dmeans3D), ("shs", shs, bwd.dL_dsh), ("mask", mask, bwd.dL_dmask),
+                             ("opacities", opac, bwd.dL_dopacity), ("scales", scales, bwd.dL_dscales),
+                             ("rotations", rots, bwd.dL_drotations)]:
+        hp.assert_close(name, leaf.grad.cpu().numpy(), np.asarray(want).reshape(leaf.shape), flip_frac=hp.GRAD_FLIP_FRAC)
+    # mask-only pair: only the mask receives a gradient
+    mask2 = _leaf(inp.mask, dev)
+    m_only, radii2 = rast.forward_mask(means3D=means3D.detach(), means2D=means2D.detach(), opacities=opac.detach(),
+                                       mask=mask2, scales=scales.detach(), rotations=rots.detach())
+    (m_only * torch.as_tensor(dLm).to(dev)).sum().backward()
+    fm = so.mask_forward(inp)
+    hp.assert_close("mask_only", m_only.detach().cpu().numpy(), fm.mask, flip_frac=hp.FLIP_FRAC)
+    hp.assert_close("mask_only grad", mask2.grad.cpu().numpy(), so.mask_backward(inp, fm, dLm[0]), flip_frac=hp.GRAD_FLIP_FRAC)
+
+
+def test_debug_flag_and_error_snapshot(tmp_path, monkeypatch):
+    import diff_gaussian_rasterization_contrastive_f as mod
+    dev = torch.device("cuda:0")
+    inp = hp.make_inputs(500, 64, 48, 32, seed=33)
+    monkeypatch.chdir(tmp_path)
+    rast = mod.GaussianRasterizer(raster_settings=_settings(mod, inp, dev, debug=True))
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    color, _ = rast(means3D=t(inp.means3D), means2D=t(inp.means3D) * 0, shs=None, colors_precomp=t(inp.colors_precomp),
+                    opacities=t(inp.opacities), scales=t(inp.scales), rotations=t(inp.rotations), cov3D_precomp=None)
+    hp.assert_close("color(debug)", color.cpu().numpy(), so.forward(inp).color, flip_frac=hp.FLIP_FRAC)
+    # SH input to the 32-channel package: the reference's runtime_error, plus the debug snapshot file
+    with pytest.raises(RuntimeError, match="For non-RGB, provide precomputed Gaussian colors!"):
+        rast(means3D=t(inp.means3D), means2D=t(inp.means3D) * 0, shs=torch.zeros(500, 1, 3, device=dev), colors_precomp=None,
+             opacities=t(inp.opacities), scales=t(inp.scales), rotations=t(inp.rotations), cov3D_precomp=None)
+    assert os.path.exists("snapshot_fw.dump")
+    dump = torch.load("snapshot_fw.dump", weights_only=False)
+    assert len(dump) == 19 and dump[1].shape == (500, 3)
