@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Turns gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/:
+   profiles/<tag>_kernel_stats.md   per-kernel time table (rocprofv3 --kernel-trace --stats)
+   profiles/<tag>_pmc.md            PMC counters of the hot kernels
+   profiles/traffic.json            HBM bytes per launch per stage (FETCH_SIZE / WRITE_SIZE passes), read by bench.py
+"""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(n):
+    n = re.sub(r"\(.*", "", n).replace("void ", "")
+    if "onesweep_iteration" in n: return "rocprim::radix_sort_onesweep_iteration (depth sort of P keys)"
+    if "onesweep_global" in n or "onesweep_hist" in n: return "rocprim::radix_sort_onesweep_histograms"
+    if "rocprim" in n: return "rocprim::" + n.split("::")[-1][:50]
+    return n[:90]
+
+
+STAGE_OF = {"blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd",
+            "preprocess_fwd_kernel": "preprocess", "emit_ranks_kernel": "emit", "tile_sort_kernel": "tile_sort",
+            "tile_scan_kernel": "tile_scan", "geometry_bwd_kernel": "geom_bwd"}
+
+rows = list(csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))))
+agg = {}
+for r in rows:
+    a = agg.setdefault(short(r["Name"]), [0, 0]); a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
+tot = sum(v[1] for v in agg.values())
+bench_line = open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1]
+with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats ({tag})\n\n")
+    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline` "
+            "on 1x MI355X (BASELINE cfg3: 1M Gaussians, 1920x1080, 32-D, fwd+bwd). Kernel names shortened; template "
+            "instances of one kernel merged. Each bench step launches every kernel once; calls also include the warm-up, "
+            "the per-stage timing steps and one counter step.\n\n")
+    f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        f.write(f"| `{k}` | {c} | {t/1e6:.3f} | {t/c/1e3:.1f} | {100*t/tot:.2f} |\n")
+    f.write("\nUn-profiled bench line of the same build (`python bench.py --steps 20 --warmup 3`):\n\n```json\n" + bench_line + "\n```\n")
+
+
+def pmc(name):
+    path = os.path.join(src, f"{name}_counter_collection.csv")
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not os.path.exists(path):
+        return out
+    for r in csv.DictReader(open(path)):
+        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("mirast::", "")
+        k = re.sub(r"<.*", "", k)
+        out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+fetch, write = pmc("fetch"), pmc("write")
+traffic = {}
+with open(os.path.join(dst, f"{tag}_pmc.md"), "w") as f:
+    f.write(f"# rocprofv3 PMC passes ({tag})\n\nSeparate passes per counter group (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, two SQ groups), "
+            "`--kernel-trace` only, same bench command. FETCH_SIZE / WRITE_SIZE are in KiB per dispatch (averaged over the "
+            "dispatches of a kernel). Per `/opt/skills/guides/MI355X_MICROARCH.md` (HBM): on gfx950 FETCH_SIZE reports exactly "
+            "half of the bytes of a wide coalesced stream (it tallies 128-B requests at 64 B), so `traffic = (2*FETCH_SIZE + "
+            "WRITE_SIZE) * 1024`; the uncorrected sum is listed too. Infinity-Cache hits are counted, not excluded.\n\n")
+    f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic corrected MB | uncorrected MB |\n|---|---|---|---|---|\n")
+    for k in sorted(set(fetch) | set(write)):
+        fs = fetch[k].get("FETCH_SIZE", [0]); ws = write[k].get("WRITE_SIZE", [0])
+        fa, wa = sum(fs) / len(fs), sum(ws) / len(ws)
+        corr, raw = (2 * fa + wa) * 1024, (fa + wa) * 1024
+        f.write(f"| `{k}` | {fa:.0f} | {wa:.0f} | {corr/1e6:.1f} | {raw/1e6:.1f} |\n")
+        st = STAGE_OF.get(k)
+        if st:
+            t = traffic.setdefault(st, {"bytes_per_launch": 0.0, "kernels": []})
+            t["bytes_per_launch"] += corr; t["kernels"].append(k)
+    for name in ("sq1", "sq2"):
+        p = pmc(name)
+        if not p: continue
+        f.write(f"\n## SQ counters ({name}); per dispatch averages, summed over the chip as rocprofv3 reports them\n\n")
+        for k, cs in p.items():
+            f.write(f"**{k}**\n\n| counter | value |\n|---|---|\n")
+            for c, v in sorted(cs.items()):
+                f.write(f"| {c} | {sum(v)/len(v):.0f} |\n")
+            f.write("\n")
+for st in traffic.values():
+    st["bytes_per_launch"] = round(st["bytes_per_launch"])
+traffic["_source"] = f"profiles/{tag}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note)"
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_kernel_stats.md")).read()[:3000])
+print(json.dumps(traffic, indent=1))
