@@ -144,14 +144,52 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int gx, int gy, const i
     if (tid == 0) *num_rendered = (int)s_carry;
 }
 
+// A survivor of the exact-conservative cull (cull.h), as the blend kernels consume it: everything needed to
+// evaluate the Gaussian at a pixel in ONE coalesced 32-byte record (the reference gathers id -> xy -> conic
+// per batch with dependent loads, forward.cu:318-326).
+struct __attribute__((aligned(16))) BlendRec {
+    float2 xy;       // pixel-space mean
+    uint32_t id;     // Gaussian index (feature row)
+    uint32_t pm;     // (position in the tile list) << 4 | quadrant mask
+    float4 co;       // conic A,B,C + opacity
+};
+static_assert(sizeof(BlendRec) == 32, "BlendRec must be 32 bytes");
+
+// ---- per-rank geometry records ------------------------------------------------------------------------
+// After the depth sort, the per-Gaussian data the binning stages need (pixel mean, conic, opacity, radius, id)
+// is permuted ONCE into rank order as 32-byte records.  Rank emission then reads them coalesced, and the per-tile
+// sort gathers ONE 32-byte sector per list entry at monotonically increasing addresses instead of three dependent
+// random gathers (sorted_idx -> means2D -> conic_opacity; measured: that gather, not the radix passes, was 0.3 of
+// the 0.34 ms of the tile sort kernel).  The record layout is the blend record's; `pm` holds the radius here.
+__global__ void __launch_bounds__(256) build_rank_records_kernel(int P, const uint32_t* __restrict__ sorted_idx,
+                                                                 const float2* __restrict__ points_xy,
+                                                                 const float4* __restrict__ conic_opacity,
+                                                                 const int* __restrict__ radii, BlendRec* __restrict__ rank_rec)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P) return;
+    const uint32_t g = sorted_idx[r];
+    const int rad = radii[g];
+    BlendRec rec;
+    rec.id = g;
+    rec.pm = (uint32_t)(rad > 0 ? rad : 0);
+    if (rad > 0) {
+        rec.xy = points_xy[g];
+        rec.co = conic_opacity[g];
+    } else {
+        rec.xy = make_float2(0.f, 0.f);
+        rec.co = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    rank_rec[r] = rec;
+}
+
 // ---- 4. rank emission ------------------------------------------------------------------------------
 // Thread r handles the Gaussian of depth rank r (sorted_idx[r]); ranks >= V map to culled Gaussians.  One global
 // returning atomic per overlap: lanes walking a rect row hit consecutive cursors, which the L2 handles as one line
 // operation.  (Tried and rejected: privatising the cursors in LDS with persistent workgroups -- the per-(workgroup,
 // tile) reservation atomics and the two LDS-atomic walks made it 2x slower, 0.51 ms vs 0.24 ms.)
-__global__ void __launch_bounds__(256) emit_ranks_kernel(int P, const uint32_t* __restrict__ sorted_idx,
-                                                         const float2* __restrict__ points_xy,
-                                                         const int* __restrict__ radii, const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(256) emit_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
+                                                         const uint2* __restrict__ ranges,
                                                          uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ entries,
                                                          uint32_t gx, uint32_t gy)
 {
@@ -161,11 +199,10 @@ __global__ void __launch_bounds__(256) emit_ranks_kernel(int P, const uint32_t* 
     uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
     uint32_t count = 0;
     if (r < P) {
-        const uint32_t g = sorted_idx[r];
-        const int rad = radii[g];
+        const BlendRec rec = rank_rec[r];
+        const int rad = (int)rec.pm;
         if (rad > 0) {
-            const float2 p = points_xy[g];
-            getRect(p.x, p.y, rad, rmin, rmax, gx, gy);
+            getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
             count = (rmax.x - rmin.x) * (rmax.y - rmin.y);
         }
     }
@@ -252,24 +289,11 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
     __syncthreads();
 }
 
-// A survivor of the exact-conservative cull (cull.h), as the blend kernels consume it: everything needed to
-// evaluate the Gaussian at a pixel in ONE coalesced 32-byte record (the reference gathers id -> xy -> conic
-// per batch with dependent loads, forward.cu:318-326).
-struct __attribute__((aligned(16))) BlendRec {
-    float2 xy;       // pixel-space mean
-    uint32_t id;     // Gaussian index (feature row)
-    uint32_t pm;     // (position in the tile list) << 4 | quadrant mask
-    float4 co;       // conic A,B,C + opacity
-};
-static_assert(sizeof(BlendRec) == 32, "BlendRec must be 32 bytes");
-
 // Emits point_list (the reference-exact sorted id list) and, in the same pass, the compacted blend list of the
 // tile: entries whose quadrant mask is non-zero, in list order, at blend_rec[range.x ...], count in blend_count.
 template <typename SrcPtr>
 __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_ranks, int n, uint2 range, int tid,
-                                                const uint32_t* __restrict__ sorted_idx,
-                                                const float2* __restrict__ points_xy,
-                                                const float4* __restrict__ conic_opacity,
+                                                const BlendRec* __restrict__ rank_rec,
                                                 uint32_t* __restrict__ point_list, BlendRec* __restrict__ blend_rec,
                                                 uint32_t* __restrict__ blend_count, uint32_t tile, uint32_t gx,
                                                 uint32_t* s_wcount)
@@ -285,10 +309,11 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_ranks, int n, uint
         float2 xy = make_float2(0.f, 0.f);
         float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n) {
-            g = sorted_idx[sorted_ranks[i]];
+            const BlendRec rr = rank_rec[sorted_ranks[i]];
+            g = rr.id;
             out[i] = g;
-            xy = points_xy[g];
-            co = conic_opacity[g];
+            xy = rr.xy;
+            co = rr.co;
             qmask = quadrant_mask(xy, co, tile_px, tile_py);
         }
         int ns;
@@ -310,10 +335,8 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_ranks, int n, uint
 template <int LO, int CAP, bool GLOBAL_FALLBACK>
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ entries,
                                                         uint32_t* __restrict__ scratch,
-                                                        const uint32_t* __restrict__ sorted_idx,
+                                                        const BlendRec* __restrict__ rank_rec,
                                                         uint32_t* __restrict__ point_list, int passes,
-                                                        const float2* __restrict__ points_xy,
-                                                        const float4* __restrict__ conic_opacity,
                                                         BlendRec* __restrict__ blend_rec,
                                                         uint32_t* __restrict__ blend_count, uint32_t gx)
 {
@@ -339,8 +362,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
             a = b;
             b = t;
         }
-        emit_tile_lists(a, n, range, tid, sorted_idx, points_xy, conic_opacity, point_list, blend_rec, blend_count,
-                        blockIdx.x, gx, s_wcount);
+        emit_tile_lists(a, n, range, tid, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, gx, s_wcount);
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
@@ -350,8 +372,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
             a = b;
             b = t;
         }
-        emit_tile_lists(a, n, range, tid, sorted_idx, points_xy, conic_opacity, point_list, blend_rec, blend_count,
-                        blockIdx.x, gx, s_wcount);
+        emit_tile_lists(a, n, range, tid, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, gx, s_wcount);
     }
 }
 

@@ -141,6 +141,7 @@ struct GeomPtrs {
     char* sort_temp;
     size_t sort_temp_size;
     float* bwd_pack;  // [P,8] packed per-Gaussian field gradients (backward scratch)
+    BlendRec* rank_rec;  // [P] geometry records in depth-rank order (binning.h)
 };
 struct ImgPtrs {
     float* final_T;
@@ -179,6 +180,7 @@ GeomPtrs geom_from(char* base, int P)
     g.sort_temp = base + off[MI_GEOM_SORT_TEMP];
     g.sort_temp_size = depth_sort_temp_bytes(P);
     g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
+    g.rank_rec = (BlendRec*)(base + off[MI_GEOM_RANK_REC]);
     return g;
 }
 ImgPtrs img_from(char* base, int W, int H)
@@ -280,6 +282,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         StageTimer t(stream, MI_STAGE_DEPTH_SORT);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(geom.sort_temp, geom.sort_temp_size, geom.depth_key, geom.sorted_key,
                                                    geom.idx_iota, geom.sorted_idx, P, 0, 32, stream));
+        hipLaunchKernelGGL(build_rank_records_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.sorted_idx,
+                           geom.means2D, geom.conic_opacity, radii, geom.rank_rec);
     }
     STAGE_CHECK("depth sort");
     // rasterizer_impl.cu:280-281: the host needs num_rendered to size the binning buffer.  We wait only for
@@ -296,21 +300,22 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            hipLaunchKernelGGL(emit_ranks_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.sorted_idx,
-                               geom.means2D, radii, img.ranges, img.tile_cursor, bin.entries, vp.grid_x, vp.grid_y);
+            hipLaunchKernelGGL(emit_ranks_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.rank_rec,
+                               img.ranges, img.tile_cursor, bin.entries, vp.grid_x, vp.grid_y);
         }
         STAGE_CHECK("emit ranks");
         int rank_bits = 1;
         while ((1ll << rank_bits) < (long long)P) rank_bits++;
-        const int passes = (rank_bits + 7) / 8;
+        int passes = (rank_bits + 7) / 8;
+        if (g_ablate_fwd & 256) passes = 0;  // timing experiment: skip the radix passes (wrong order)
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
             hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                               bin.entries, bin.scratch, geom.sorted_idx, bin.point_list, passes, geom.means2D,
-                               geom.conic_opacity, bin.blend_rec, img.blend_count, vp.grid_x);
+                               bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
+                               img.blend_count, vp.grid_x);
             hipLaunchKernelGGL((tile_sort_kernel<2048, 12288, true>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                               bin.entries, bin.scratch, geom.sorted_idx, bin.point_list, passes, geom.means2D,
-                               geom.conic_opacity, bin.blend_rec, img.blend_count, vp.grid_x);
+                               bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
+                               img.blend_count, vp.grid_x);
         }
         STAGE_CHECK("tile sort");
     }
@@ -382,6 +387,7 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_SORTED_IDX] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_SORT_TEMP] = c.take(depth_sort_temp_bytes(P) + 16);
     off[MI_GEOM_BWD_PACK] = c.take(p * 8 * sizeof(float));
+    off[MI_GEOM_RANK_REC] = c.take(p * sizeof(BlendRec));
     return c.off;
 }
 size_t mi_rast_image_layout(int width, int height, size_t* off)
