@@ -96,8 +96,10 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int gx, int gy, const i
     extern __shared__ int s_grid[];  // (gy+1) x (gx+1)
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_maxcount;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gw = gx + 1, gh = gy + 1, ntiles = gx * gy;
+    if (tid == 0) s_maxcount = 0;
     for (int i = tid; i < gw * gh; i += 1024) s_grid[i] = diff_grid[(size_t)i * GRID_STRIDE];
     if (tid == 0) s_carry = 0;
     __syncthreads();
@@ -137,11 +139,20 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int gx, int gy, const i
             ranges[t] = c ? make_uint2(excl, excl + c) : make_uint2(0u, 0u);
             tile_cursor[t] = 0u;
         }
+        {
+            uint32_t m = c;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+            if (lane == 0 && m) atomicMax(&s_maxcount, m);
+        }
         __syncthreads();
         if (tid == 1023) s_carry = excl + c;
         __syncthreads();
     }
-    if (tid == 0) *num_rendered = (int)s_carry;
+    if (tid == 0) {
+        num_rendered[0] = (int)s_carry;       // R
+        num_rendered[1] = (int)s_maxcount;    // longest tile list: lets the host skip unused sort size classes
+    }
 }
 
 // A survivor of the exact-conservative cull (cull.h), as the blend kernels consume it: everything needed to

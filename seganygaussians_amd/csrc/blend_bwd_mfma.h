@@ -31,6 +31,9 @@ constexpr int RB2 = 128;   // blend-list records per batch
 constexpr int FROW = 36;   // padded feature row (floats): conflict-free 16-lane b128 operand reads
 constexpr int WROW = 68;   // padded w/u row (floats)
 constexpr int CHK = 16;    // rows per MFMA chunk
+constexpr int DLROW = 33;  // padded gradient-image staging row (floats)
+constexpr int POOL4 = RB2 * FROW / 4 + 4 * CHK * WROW / 4;
+static_assert(POOL4 * 4 >= 4 * 64 * DLROW, "gradient-image staging must fit in the aliased buffers");
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -38,17 +41,18 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
     int W, int H, const float* __restrict__ bg_color, const float* __restrict__ colors,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-    float* __restrict__ gpack /*[P,8] packed field gradients*/, float* __restrict__ dL_dcolors)
+    float* __restrict__ gpack /*[P,8] packed field gradients*/, float* __restrict__ dL_dcolors,
+    int ablate /* timing experiments only; 0 in production */)
 {
     constexpr int C = 32;
     __shared__ float2 s_xy[RB2];
     __shared__ float4 s_co[RB2];
     __shared__ uint32_t s_id[RB2];
     __shared__ uint32_t s_pm[RB2];
-    __shared__ float4 s_feat4[RB2 * FROW / 4];
+    __shared__ float4 s_pool[POOL4];  // feature rows | per-wave w rows  (prologue: gradient-image staging)
+    float4* const s_feat4 = s_pool;
     __shared__ uint64_t s_bits[4][RB2 / 64];
     __shared__ uint8_t s_list[4][RB2];
-    __shared__ float4 s_wa4[4][CHK * WROW / 4];
     __shared__ float4 s_ua4[4][CHK * WROW / 4];
     __shared__ float4 s_mom4[4][CHK * 8 / 4];
     __shared__ int s_maxc;
@@ -80,53 +84,39 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
     const float T_final = inside ? final_Ts[pix_id] : 0;
     float T = T_final;
 
-    // ---- gradient image of this quadrant in the two MFMA operand layouts
+    // ---- gradient image of this quadrant: one coalesced pass (lane = pixel, 32 loads), staged through LDS into
+    // the two MFMA operand layouts.  The staging rows alias the feature / w-row buffers, which are first written
+    // after the barrier that opens the batch loop.
     const int n16 = lane & 15, kq = lane >> 4;
-    auto pix_of = [&](int i, bool& in) -> size_t {  // quadrant-local pixel index (== lane index of its owner)
-        const uint32_t x = qx0 + (i & 7), y = qy0 + (i >> 3);
-        in = x < (uint32_t)W && y < (uint32_t)H;
-        return in ? (size_t)W * y + x : 0;
-    };
-    // B of the S contraction: dLB[pb][s] = dL[pixel 16*pb + n16][channel 8*kq + s]
-    float dLB[4][8];
-#pragma unroll
-    for (int pb = 0; pb < 4; pb++) {
-        bool in;
-        const size_t p = pix_of(16 * pb + n16, in);
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const float v = dL_dpixels[(size_t)(8 * kq + s) * HW + p];
-            dLB[pb][s] = in ? v : 0.f;
-        }
-    }
-    // B of the dF contraction: dLT[nb][s] = dL[pixel 16*kq + s][channel 16*nb + n16]
-    float dLT[2][16];
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-        bool in;
-        const size_t p = pix_of(16 * kq + s, in);
-#pragma unroll
-        for (int nb = 0; nb < 2; nb++) {
-            const float v = dL_dpixels[(size_t)(16 * nb + n16) * HW + p];
-            dLT[nb][s] = in ? v : 0.f;
-        }
-    }
-    // bg . dL of this lane's own pixel (backward.cu:533-535)
-    float bg_dot_dpixel = 0.f;
+    float dLB[4][8];   // B of the S contraction:  dLB[pb][s] = dL[pixel 16*pb + n16][channel 8*kq + s]
+    float dLT[2][16];  // B of the dF contraction: dLT[nb][s] = dL[pixel 16*kq + s][channel 16*nb + n16]
+    float bg_dot_dpixel = 0.f;  // bg . dL of this lane's own pixel (backward.cu:533-535)
     {
+        float* stage = reinterpret_cast<float*>(s_pool) + wave * (64 * DLROW);
         const size_t pix_safe = inside ? pix_id : 0;
-#pragma unroll 8
+#pragma unroll
         for (int ch = 0; ch < C; ch++) {
-            const float v = dL_dpixels[(size_t)ch * HW + pix_safe];
-            bg_dot_dpixel += bg_color[ch] * (inside ? v : 0.f);
+            const float v0 = dL_dpixels[(size_t)ch * HW + pix_safe];
+            const float v = inside ? v0 : 0.f;
+            bg_dot_dpixel += bg_color[ch] * v;
+            stage[lane * DLROW + ch] = v;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int pb = 0; pb < 4; pb++)
+#pragma unroll
+            for (int s = 0; s < 8; s++) dLB[pb][s] = stage[(16 * pb + n16) * DLROW + 8 * kq + s];
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) dLT[nb][s] = stage[(16 * kq + s) * DLROW + 16 * nb + n16];
     }
 
     float last_alpha = 0.f, S_last = 0.f, Rrec = 0.f;
     const float ddelx_dx = 0.5 * W;  // backward.cu:460-461
     const float ddely_dy = 0.5 * H;
     const float cxq = (float)qx0 + 3.5f, cyq = (float)qy0 + 3.5f;  // moment origin: quadrant centre
-    float* my_wa = reinterpret_cast<float*>(s_wa4[wave]);
+    float* my_wa = reinterpret_cast<float*>(s_pool + RB2 * FROW / 4 + wave * (CHK * WROW / 4));
     float* my_ua = reinterpret_cast<float*>(s_ua4[wave]);
     float* my_mom = reinterpret_cast<float*>(s_mom4[wave]);
 
@@ -158,7 +148,7 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
             for (int k = 0; k < RB2 * 8 / BATCH; k++) {
                 const int q = tid + BATCH * k;
                 const int g = q >> 3, part = q & 7;
-                if (g < nr)
+                if (g < nr && !(ablate & 4))
                     s_feat4[g * (FROW / 4) + part] = reinterpret_cast<const float4*>(colors + (size_t)rec[NS - 1 - (b0 + g)].id * C)[part];
             }
         }
@@ -177,6 +167,7 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
         }
         cnt = __builtin_amdgcn_readfirstlane(cnt);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (ablate & 1) cnt = 0;
 
         for (int j0 = 0; j0 < cnt; j0 += CHK) {
             const int nrow = min(CHK, cnt - j0);
@@ -244,7 +235,7 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
             }
             rowmask = __builtin_amdgcn_readfirstlane(rowmask);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (rowmask == 0) continue;
+            if (rowmask == 0 || (ablate & 2)) continue;
 
             // ---- 3. dF = W^T . dL  and  M = U^T . Phi   (A rows from LDS, lane (m = n16, kq) reads pixels 16kq..16kq+15)
             v4f facc[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};

@@ -276,7 +276,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     }
     STAGE_CHECK("tile scan");
     if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host word / event");
-    HIP_TRY(hipMemcpyAsync(g_host_sync.pinned, img.num_rendered, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(g_host_sync.pinned, img.num_rendered, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
     {
         StageTimer t(stream, MI_STAGE_DEPTH_SORT);
@@ -289,7 +289,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     // rasterizer_impl.cu:280-281: the host needs num_rendered to size the binning buffer.  We wait only for
     // the copy (event), not for the depth sort queued behind it.
     HIP_TRY(hipEventSynchronize(g_host_sync.ev));
-    const int R = *g_host_sync.pinned;
+    const int R = g_host_sync.pinned[0];
+    const int max_tile_count = g_host_sync.pinned[1];
     *num_rendered = R;
 
     size_t boff[MI_BIN_NFIELDS];
@@ -310,12 +311,19 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         if (g_ablate_fwd & 256) passes = 0;  // timing experiment: skip the radix passes (wrong order)
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
+            // three list-length classes (LDS footprint 20 / 52 / 100 KB per workgroup); a class is launched only
+            // if some tile needs it (the scan kernel reports the longest list together with R)
             hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
                                bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
                                img.blend_count, vp.grid_x);
-            hipLaunchKernelGGL((tile_sort_kernel<2048, 12288, true>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                               bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
-                               img.blend_count, vp.grid_x);
+            if (max_tile_count > 2048)
+                hipLaunchKernelGGL((tile_sort_kernel<2048, 6144, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
+                                   bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
+                                   img.blend_count, vp.grid_x);
+            if (max_tile_count > 6144)
+                hipLaunchKernelGGL((tile_sort_kernel<6144, 12288, true>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
+                                   bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
+                                   img.blend_count, vp.grid_x);
         }
         STAGE_CHECK("tile sort");
     }
@@ -524,7 +532,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         else if (channels == 32 && !(g_ablate & 1024))
             hipLaunchKernelGGL(blend_bwd32_mfma_kernel, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
                                bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib,
-                               dL_dpix, geom.bwd_pack, dL_dcolor);
+                               dL_dpix, geom.bwd_pack, dL_dcolor, g_ablate);
         else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
         else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
     }
