@@ -172,10 +172,16 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
         for (int j0 = 0; j0 < cnt; j0 += CHK) {
             const int nrow = min(CHK, cnt - j0);
             // ---- 1. S = F . dL^T  (16 rows x 64 pixels, K = 32 channels)
+            // Row parameters live in registers: lane r (and its 3 copies r + 16k) holds row r of the chunk; the
+            // recurrence below broadcasts them with v_readlane instead of waiting on LDS once per row.
+            const int jr = j0 + n16;
+            const int km = s_list[wave][jr < cnt ? jr : j0];
+            const float2 rxy = s_xy[km];
+            const float4 rco = s_co[km];
+            const int rpos = jr < cnt ? (int)(s_pm[km] >> 4) : 0x7fffffff;  // rows past the end never validate
+            const uint32_t rid = s_id[km];
             v4f sacc[4];
             {
-                const int jr = j0 + n16;  // this lane's operand row
-                const int km = s_list[wave][jr < cnt ? jr : j0];
                 const float4 fa0 = s_feat4[km * (FROW / 4) + 2 * kq];
                 const float4 fa1 = s_feat4[km * (FROW / 4) + 2 * kq + 1];
                 const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
@@ -207,29 +213,29 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
             uint32_t rowmask = 0;
 #pragma unroll
             for (int rr = 0; rr < CHK; rr++) {
-                float w = 0.f, u = 0.f;
-                if (rr < nrow) {
-                    const int k = __builtin_amdgcn_readfirstlane((int)s_list[wave][j0 + rr]);
-                    const float2 cxy = s_xy[k];
-                    const float4 cco = s_co[k];
-                    const int pos = (int)(s_pm[k] >> 4);
-                    const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
-                    const float power = -0.5f * (cco.x * dx * dx + cco.z * dy * dy) - cco.y * dx * dy;
-                    const float G = __expf(power);
-                    const float alpha = fminf(0.99f, cco.w * G);
-                    const bool valid = (pos < last_contributor) && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                    const float one_m_alpha_inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = valid ? T * one_m_alpha_inv : T;
-                    w = valid ? alpha * T : 0.f;  // dchannel_dcolor
-                    const float S = Srow[rr];
-                    Rrec = valid ? (last_alpha * S_last + (1.f - last_alpha) * Rrec) : Rrec;
-                    float dL_dalpha = (S - Rrec) * T;
-                    S_last = valid ? S : S_last;
-                    last_alpha = valid ? alpha : last_alpha;
-                    dL_dalpha += (-T_final * one_m_alpha_inv) * bg_dot_dpixel;
-                    u = valid ? cco.w * dL_dalpha * G : 0.f;  // dL/dG * G
-                    rowmask |= (ballot64(valid) != 0 ? 1u : 0u) << rr;
-                }
+                const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rxy.x), rr));
+                const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rxy.y), rr));
+                const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rco.x), rr));
+                const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rco.y), rr));
+                const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rco.z), rr));
+                const float op = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rco.w), rr));
+                const int pos = __builtin_amdgcn_readlane(rpos, rr);
+                const float dx = cx - pixfx, dy = cy - pixfy;
+                const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, op * G);
+                const bool valid = (pos < last_contributor) && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                const float one_m_alpha_inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = valid ? T * one_m_alpha_inv : T;
+                const float w = valid ? alpha * T : 0.f;  // dchannel_dcolor
+                const float S = Srow[rr];
+                Rrec = valid ? (last_alpha * S_last + (1.f - last_alpha) * Rrec) : Rrec;
+                float dL_dalpha = (S - Rrec) * T;
+                S_last = valid ? S : S_last;
+                last_alpha = valid ? alpha : last_alpha;
+                dL_dalpha += (-T_final * one_m_alpha_inv) * bg_dot_dpixel;
+                const float u = valid ? op * dL_dalpha * G : 0.f;  // dL/dG * G
+                rowmask |= (ballot64(valid) != 0 ? 1u : 0u) << rr;
                 my_wa[rr * WROW + lane] = w;
                 my_ua[rr * WROW + lane] = u;
             }
@@ -273,8 +279,7 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
             for (int r = 0; r < 4; r++) {
                 const int row = 4 * kq + r;
                 const bool act = (rowmask >> row) & 1u;
-                const int krow = s_list[wave][j0 + (row < nrow ? row : 0)];
-                const uint32_t gid = s_id[krow];
+                const uint32_t gid = (uint32_t)__shfl((int)rid, row, 64);
                 if (act) {
                     atomicAdd(&dL_dcolors[(size_t)gid * C + n16], facc[0][r]);
                     atomicAdd(&dL_dcolors[(size_t)gid * C + 16 + n16], facc[1][r]);
@@ -288,12 +293,11 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
                 const int row = lane & 15;
                 const bool act = lane < 16 && ((rowmask >> row) & 1u);
                 if (act) {
-                    const int krow = s_list[wave][j0 + row];
                     const float4 m0 = reinterpret_cast<const float4*>(my_mom + row * 8)[0];
                     const float4 m1 = reinterpret_cast<const float4*>(my_mom + row * 8)[1];
                     const float M0 = m0.x, M1 = m0.y, M2 = m0.z, M3 = m0.w, M4 = m1.x, M5 = m1.y;
-                    const float2 gxy = s_xy[krow];
-                    const float4 gco = s_co[krow];
+                    const float2 gxy = rxy;
+                    const float4 gco = rco;
                     const float gx = gxy.x - cxq, gy = gxy.y - cyq;
                     // dx = gx - x', dy = gy - y'
                     const float Sdx = gx * M0 - M1;
@@ -317,10 +321,8 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
 #pragma unroll
                 for (int it = 0; it < 2; it++) {
                     const int row2 = 8 * it + (lane >> 3), f = lane & 7;
-                    if (((rowmask >> row2) & 1u) && f < 6) {
-                        const int krow = s_list[wave][j0 + row2];
-                        atomicAdd(&gpack[(size_t)s_id[krow] * 8 + f], my_mom[row2 * 8 + f]);
-                    }
+                    const uint32_t gid2 = (uint32_t)__shfl((int)rid, row2, 64);
+                    if (((rowmask >> row2) & 1u) && f < 6) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * 8 + f]);
                 }
             }
         }
