@@ -25,19 +25,36 @@
 #include "blend_fwd.h"
 #include "common.h"
 
+#ifndef BWD_WAVES_PER_SIMD
+#define BWD_WAVES_PER_SIMD 3
+#endif
+
 namespace mirast {
 
-constexpr int RB2 = 128;   // blend-list records per batch
+constexpr int RB2 = 80;    // blend-list records per batch (LDS budget of 3 workgroups per CU)
 constexpr int FROW = 36;   // padded feature row (floats): conflict-free 16-lane b128 operand reads
 constexpr int WROW = 68;   // padded w/u row (floats)
 constexpr int CHK = 16;    // rows per MFMA chunk
 constexpr int DLROW = 33;  // padded gradient-image staging row (floats)
-constexpr int POOL4 = RB2 * FROW / 4 + 4 * CHK * WROW / 4;
+constexpr int NBITS = (RB2 + 63) / 64;
+constexpr int FEAT4 = (RB2 + 1) * FROW / 4;  // + one all-zero row for the list padding
+constexpr int POOL4 = FEAT4 + 2 * 4 * CHK * WROW / 4;
 static_assert(POOL4 * 4 >= 4 * 64 * DLROW, "gradient-image staging must fit in the aliased buffers");
+static_assert(RB2 + FROW / 4 <= 256, "staging roles are assigned by thread index");
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
+// One staged record: {x, y, conic a, conic b} {conic c, opacity, list position (int bits), Gaussian id (int bits)}
+struct BwdPar {
+    float4 q0, q1;
+};
+
+// VALU issue is the limiter of this kernel: a wave issues one VALU instruction per ~8 cycles, a SIMD reaches
+// 4.25 / 3.5 / 2.7 cycles per instruction with 2 / 3 / 4 resident waves, and an f32 MFMA occupies the same ALUs
+// for its full 32 cycles (tools/valu_rate_probe.hip, tools/interleave_probe.hip, tools/overlap_probe.hip).  Hence:
+// few instructions per (row, pixel), row parameters fetched by LDS broadcast reads (not VALU), no selects where
+// arithmetic with alpha = 0 does the same, and the register budget of 3 waves per SIMD.
+__global__ void __launch_bounds__(256, BWD_WAVES_PER_SIMD) blend_bwd32_mfma_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
     int W, int H, const float* __restrict__ bg_color, const float* __restrict__ colors,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
@@ -45,17 +62,13 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
     int ablate /* timing experiments only; 0 in production */)
 {
     constexpr int C = 32;
-    __shared__ float2 s_xy[RB2];
-    __shared__ float4 s_co[RB2];
-    __shared__ uint32_t s_id[RB2];
-    __shared__ uint32_t s_pm[RB2];
-    __shared__ float4 s_pool[POOL4];  // feature rows | per-wave w rows  (prologue: gradient-image staging)
-    float4* const s_feat4 = s_pool;
-    __shared__ uint64_t s_bits[4][RB2 / 64];
-    __shared__ uint8_t s_list[4][RB2];
-    __shared__ float4 s_ua4[4][CHK * WROW / 4];
+    __shared__ BwdPar s_par[RB2 + 1];                // [RB2] = padding record (never valid)
+    __shared__ float4 s_pool[POOL4];                 // feature rows | w rows | u rows  (prologue: gradient-image staging)
+    __shared__ uint64_t s_bits[4][NBITS];
+    __shared__ uint16_t s_list[4][RB2 + CHK];        // per quadrant: BYTE OFFSETS of its records in s_par, back to front
     __shared__ float4 s_mom4[4][CHK * 8 / 4];
-    __shared__ int s_maxc;
+    __shared__ int s_Lt[4];
+    float4* const s_feat4 = s_pool;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -68,24 +81,33 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     const size_t HW = (size_t)H * W;
 
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    const bool prof = (ablate & 32) != 0;
+    long long tmark = prof ? clock64() : 0;
+#define TK(i) do { if (prof) { const long long t_ = clock64(); tk[i] += t_ - tmark; tmark = t_; } } while (0)
+    // Everything the tile needs from memory is requested up front (tile header, per-pixel state, the gradient
+    // image); the first batch of records follows as soon as the header is back.  A dependent global access costs
+    // ~4 us in this kernel, so the prologue is organised as two round trips, not five.
     const uint2 range = ranges[tile];
-    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
-    if (tid == 0) s_maxc = 0;
-    __syncthreads();
+    const int NS = (int)tile_nsurv[tile];
+    const size_t pix_safe = inside ? pix_id : 0;
+    const int last_contributor = inside ? (int)n_contrib[pix_safe] : 0;
+    const float T_final = inside ? final_Ts[pix_safe] : 0;
+    float dLpix[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) dLpix[ch] = dL_dpixels[(size_t)ch * HW + pix_safe];
+    const BlendRec* rec = blend_rec + range.x;
+    BlendRec cur;
+    if (tid < RB2 && tid < NS) cur = rec[NS - 1 - tid];
     int wave_Lt = last_contributor;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wave_Lt = max(wave_Lt, __shfl_xor(wave_Lt, o, 64));
-    if (lane == 0) atomicMax(&s_maxc, wave_Lt);
-    __syncthreads();
-    if (s_maxc == 0) return;
-    const int NS = (int)tile_nsurv[tile];
-    const BlendRec* rec = blend_rec + range.x;
-
-    const float T_final = inside ? final_Ts[pix_id] : 0;
+    if (lane == 0) s_Lt[wave] = wave_Lt;
     float T = T_final;
+    TK(0);
 
     // ---- gradient image of this quadrant: one coalesced pass (lane = pixel, 32 loads), staged through LDS into
-    // the two MFMA operand layouts.  The staging rows alias the feature / w-row buffers, which are first written
+    // the two MFMA operand layouts.  The staging rows alias the feature / w / u buffers, which are first written
     // after the barrier that opens the batch loop.
     const int n16 = lane & 15, kq = lane >> 4;
     float dLB[4][8];   // B of the S contraction:  dLB[pb][s] = dL[pixel 16*pb + n16][channel 8*kq + s]
@@ -93,15 +115,14 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
     float bg_dot_dpixel = 0.f;  // bg . dL of this lane's own pixel (backward.cu:533-535)
     {
         float* stage = reinterpret_cast<float*>(s_pool) + wave * (64 * DLROW);
-        const size_t pix_safe = inside ? pix_id : 0;
 #pragma unroll
         for (int ch = 0; ch < C; ch++) {
-            const float v0 = dL_dpixels[(size_t)ch * HW + pix_safe];
-            const float v = inside ? v0 : 0.f;
+            const float v = inside ? dLpix[ch] : 0.f;
             bg_dot_dpixel += bg_color[ch] * v;
             stage[lane * DLROW + ch] = v;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __syncthreads();  // also publishes s_Lt
+        if (max(max(s_Lt[0], s_Lt[1]), max(s_Lt[2], s_Lt[3])) == 0) return;
 #pragma unroll
         for (int pb = 0; pb < 4; pb++)
 #pragma unroll
@@ -111,29 +132,48 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
 #pragma unroll
             for (int nb = 0; nb < 2; nb++) dLT[nb][s] = stage[(16 * kq + s) * DLROW + 16 * nb + n16];
     }
+    TK(1);
+    const float nTb = -T_final * bg_dot_dpixel;  // the background term of dL/dalpha is nTb / (1 - alpha)
 
-    float last_alpha = 0.f, S_last = 0.f, Rrec = 0.f;
+    // Phi[pixel 16kq+s][j = n16] = monomial j (1, x, y, x^2, xy, y^2) about the quadrant centre, x = (s&7) - 3.5 (a
+    // literal per unrolled step), y = 2kq - 3.5 + (s>>3):  phi = P[s>>3] + Q[s>>3] x + R x^2  (exact: small dyadics)
+    float phP[2], phQ[2], phR;
+    {
+        const float c1 = n16 == 0, cx = n16 == 1, cy = n16 == 2, cxx = n16 == 3, cxy = n16 == 4, cyy = n16 == 5;
+#pragma unroll
+        for (int v = 0; v < 2; v++) {
+            const float y = (float)(2 * kq + v) - 3.5f;
+            phP[v] = c1 + cy * y + cyy * y * y;
+            phQ[v] = cx + cxy * y;
+        }
+        phR = cxx;
+    }
+
+    float Rcur = 0.f;  // sum over the Gaussians behind the current one of (their colour . dL) * their share of what is behind
     const float ddelx_dx = 0.5 * W;  // backward.cu:460-461
     const float ddely_dy = 0.5 * H;
     const float cxq = (float)qx0 + 3.5f, cyq = (float)qy0 + 3.5f;  // moment origin: quadrant centre
-    float* my_wa = reinterpret_cast<float*>(s_pool + RB2 * FROW / 4 + wave * (CHK * WROW / 4));
-    float* my_ua = reinterpret_cast<float*>(s_ua4[wave]);
+    float* my_wa = reinterpret_cast<float*>(s_pool + FEAT4 + wave * (CHK * WROW / 4));
+    float* my_ua = reinterpret_cast<float*>(s_pool + FEAT4 + (4 + wave) * (CHK * WROW / 4));
     float* my_mom = reinterpret_cast<float*>(s_mom4[wave]);
-
-    BlendRec cur;
-    if (tid < RB2 && tid < NS) cur = rec[NS - 1 - tid];
+    const char* const par_bytes = reinterpret_cast<const char*>(s_par);
 
     for (int b0 = 0; b0 < NS; b0 += RB2) {
         const int nr = min(RB2, NS - b0);  // records in this batch, walked back to front
-        __syncthreads();                   // LDS reuse
+        TK(4);
+        __syncthreads();                   // LDS reuse (first batch: the gradient-image staging reads are done)
         // ---- A: records -> LDS; next batch's record -> registers; quadrant bitmaps
         if (tid < nr) {
-            s_xy[tid] = cur.xy;
-            s_co[tid] = cur.co;
-            s_id[tid] = cur.id;
-            s_pm[tid] = cur.pm;
+            s_par[tid].q0 = make_float4(cur.xy.x, cur.xy.y, cur.co.x, cur.co.y);
+            s_par[tid].q1 = make_float4(cur.co.z, cur.co.w, __int_as_float((int)(cur.pm >> 4)), __int_as_float((int)cur.id));
         }
-        if (wave < RB2 / 64) {
+        if (tid == RB2) {  // padding record: never valid ...
+            s_par[RB2].q0 = make_float4(0.f, 0.f, 1.f, 0.f);
+            s_par[RB2].q1 = make_float4(1.f, 0.f, __int_as_float(0x7fffffff), __int_as_float(0));
+        }
+        if (tid >= 256 - FROW / 4)  // ... and its all-zero feature row (S = 0)
+            s_feat4[RB2 * (FROW / 4) + (tid - (256 - FROW / 4))] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave < NBITS) {
             const uint32_t pmv = tid < nr ? cur.pm : 0u;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -142,46 +182,41 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
             }
         }
         if (tid < RB2 && b0 + RB2 + tid < NS) cur = rec[NS - 1 - (b0 + RB2 + tid)];
-        // ---- B: feature rows (padded to FROW floats)
-        {
+        TK(2);
+        __syncthreads();
+        // ---- B: feature rows (padded to FROW floats), gathered by the ids just staged
 #pragma unroll
-            for (int k = 0; k < RB2 * 8 / BATCH; k++) {
-                const int q = tid + BATCH * k;
-                const int g = q >> 3, part = q & 7;
-                if (g < nr && !(ablate & 4))
-                    s_feat4[g * (FROW / 4) + part] = reinterpret_cast<const float4*>(colors + (size_t)rec[NS - 1 - (b0 + g)].id * C)[part];
-            }
+        for (int k = 0; k < (RB2 * 8 + BATCH - 1) / BATCH; k++) {
+            const int e = tid + BATCH * k;
+            const int g = e >> 3, part = e & 7;
+            if (g < nr && !(ablate & 4))
+                s_feat4[g * (FROW / 4) + part] = reinterpret_cast<const float4*>(colors + (size_t)__float_as_int(s_par[g].q1.w) * C)[part];
         }
         __syncthreads();
 
-        // ---- this quadrant's rows, back to front, restricted to positions below the quadrant's max n_contrib
+        // ---- this quadrant's rows, back to front, restricted to positions below the quadrant's max n_contrib;
+        //      the list is padded with CHK references to the padding record
         int cnt = 0;
 #pragma unroll
-        for (int h = 0; h < RB2 / 64; h++) {
+        for (int h = 0; h < NBITS; h++) {
             const int ridx = 64 * h + lane;
-            const bool cand = ((s_bits[wave][h] >> lane) & 1ull) && ridx < nr && (int)(s_pm[ridx < nr ? ridx : 0] >> 4) < wave_Lt;
+            const bool cand = ((s_bits[wave][h] >> lane) & 1ull) && ridx < nr && __float_as_int(s_par[ridx < nr ? ridx : 0].q1.z) < wave_Lt;
             const uint64_t b = ballot64(cand);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-            if (cand) s_list[wave][cnt + below] = (uint8_t)ridx;
+            if (cand) s_list[wave][cnt + below] = (uint16_t)(ridx * sizeof(BwdPar));
             cnt += __builtin_popcountll(b);
         }
         cnt = __builtin_amdgcn_readfirstlane(cnt);
+        if (lane < CHK) s_list[wave][cnt + lane] = (uint16_t)(RB2 * sizeof(BwdPar));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (ablate & 1) cnt = 0;
-
+        TK(3);
         for (int j0 = 0; j0 < cnt; j0 += CHK) {
-            const int nrow = min(CHK, cnt - j0);
-            // ---- 1. S = F . dL^T  (16 rows x 64 pixels, K = 32 channels)
-            // Row parameters live in registers: lane r (and its 3 copies r + 16k) holds row r of the chunk; the
-            // recurrence below broadcasts them with v_readlane instead of waiting on LDS once per row.
-            const int jr = j0 + n16;
-            const int km = s_list[wave][jr < cnt ? jr : j0];
-            const float2 rxy = s_xy[km];
-            const float4 rco = s_co[km];
-            const int rpos = jr < cnt ? (int)(s_pm[km] >> 4) : 0x7fffffff;  // rows past the end never validate
-            const uint32_t rid = s_id[km];
+            // ---- 1. S = F . dL^T  (16 rows x 64 pixels, K = 32 channels); lane (n16, kq) feeds row n16
+            const uint32_t my_off = s_list[wave][j0 + n16];
             v4f sacc[4];
             {
+                const uint32_t km = my_off / (uint32_t)sizeof(BwdPar);
                 const float4 fa0 = s_feat4[km * (FROW / 4) + 2 * kq];
                 const float4 fa1 = s_feat4[km * (FROW / 4) + 2 * kq + 1];
                 const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
@@ -209,32 +244,29 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
 
-            // ---- 2. scalar recurrences (lane = pixel), back to front
+            // ---- 2. scalar recurrences (lane = pixel), back to front.  Row parameters arrive by LDS broadcast reads.
+            // A row that does not blend into this pixel runs the same arithmetic with alpha = 0: T, R stay put, w = u = 0.
             uint32_t rowmask = 0;
 #pragma unroll
             for (int rr = 0; rr < CHK; rr++) {
-                const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rxy.x), rr));
-                const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rxy.y), rr));
-                const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rco.x), rr));
-                const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rco.y), rr));
-                const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rco.z), rr));
-                const float op = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rco.w), rr));
-                const int pos = __builtin_amdgcn_readlane(rpos, rr);
-                const float dx = cx - pixfx, dy = cy - pixfy;
-                const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+                const uint32_t off = s_list[wave][j0 + rr];
+                const float4 p0 = *reinterpret_cast<const float4*>(par_bytes + off);
+                const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + off + 16);
+                const float dx = p0.x - pixfx, dy = p0.y - pixfy;
+                const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
                 const float G = __expf(power);
-                const float alpha = fminf(0.99f, op * G);
-                const bool valid = (pos < last_contributor) && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                const float one_m_alpha_inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = valid ? T * one_m_alpha_inv : T;
-                const float w = valid ? alpha * T : 0.f;  // dchannel_dcolor
+                const float a_raw = fminf(0.99f, p1.y * G);
+                const bool valid = (__float_as_int(p1.z) < last_contributor) && power <= 0.0f && a_raw >= (1.0f / 255.0f);
+                const float alpha = valid ? a_raw : 0.f;
+                const float Ge = valid ? G : 0.f;
+                const float om = 1.f - alpha;
+                const float inv = __builtin_amdgcn_rcpf(om);
+                T = T * inv;
+                const float w = alpha * T;  // dchannel_dcolor
                 const float S = Srow[rr];
-                Rrec = valid ? (last_alpha * S_last + (1.f - last_alpha) * Rrec) : Rrec;
-                float dL_dalpha = (S - Rrec) * T;
-                S_last = valid ? S : S_last;
-                last_alpha = valid ? alpha : last_alpha;
-                dL_dalpha += (-T_final * one_m_alpha_inv) * bg_dot_dpixel;
-                const float u = valid ? op * dL_dalpha * G : 0.f;  // dL/dG * G
+                const float dL_dalpha = fmaf(nTb, inv, (S - Rcur) * T);
+                Rcur = fmaf(alpha, S, om * Rcur);
+                const float u = (p1.y * dL_dalpha) * Ge;  // dL/dG * G
                 rowmask |= (ballot64(valid) != 0 ? 1u : 0u) << rr;
                 my_wa[rr * WROW + lane] = w;
                 my_ua[rr * WROW + lane] = u;
@@ -260,27 +292,21 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
                         const int s = 4 * s4 + t;
                         facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[0][s], facc[0], 0, 0, 0);
                         facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[1][s], facc[1], 0, 0, 0);
-                        // Phi[pixel 16kq+s][j = n16]: monomials about the quadrant centre
-                        const int i = 16 * kq + s;
-                        const float xx = (float)(i & 7) - 3.5f, yy = (float)(i >> 3) - 3.5f;
-                        float phi = 0.f;
-                        phi = n16 == 0 ? 1.f : phi;
-                        phi = n16 == 1 ? xx : phi;
-                        phi = n16 == 2 ? yy : phi;
-                        phi = n16 == 3 ? xx * xx : phi;
-                        phi = n16 == 4 ? xx * yy : phi;
-                        phi = n16 == 5 ? yy * yy : phi;
+                        const float x = (float)(s & 7) - 3.5f;
+                        const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
                         macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
                     }
                 }
             }
             // ---- 4. outputs.  Result layout: lane l holds column n16 of rows 4*kq + r.
+            const BwdPar mine = *reinterpret_cast<const BwdPar*>(par_bytes + my_off);  // lane n16 = row n16
+            const int my_gid = __float_as_int(mine.q1.w);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = 4 * kq + r;
                 const bool act = (rowmask >> row) & 1u;
-                const uint32_t gid = (uint32_t)__shfl((int)rid, row, 64);
-                if (act) {
+                const uint32_t gid = (uint32_t)__shfl(my_gid, row, 64);
+                if (act && !(ablate & 64)) {
                     atomicAdd(&dL_dcolors[(size_t)gid * C + n16], facc[0][r]);
                     atomicAdd(&dL_dcolors[(size_t)gid * C + 16 + n16], facc[1][r]);
                 }
@@ -296,9 +322,8 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
                     const float4 m0 = reinterpret_cast<const float4*>(my_mom + row * 8)[0];
                     const float4 m1 = reinterpret_cast<const float4*>(my_mom + row * 8)[1];
                     const float M0 = m0.x, M1 = m0.y, M2 = m0.z, M3 = m0.w, M4 = m1.x, M5 = m1.y;
-                    const float2 gxy = rxy;
-                    const float4 gco = rco;
-                    const float gx = gxy.x - cxq, gy = gxy.y - cyq;
+                    const float ca = mine.q0.z, cb = mine.q0.w, cc = mine.q1.x, op = mine.q1.y;
+                    const float gx = mine.q0.x - cxq, gy = mine.q0.y - cyq;
                     // dx = gx - x', dy = gy - y'
                     const float Sdx = gx * M0 - M1;
                     const float Sdy = gy * M0 - M2;
@@ -306,12 +331,12 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
                     const float Sdxy = gx * gy * M0 - gx * M2 - gy * M1 + M4;
                     const float Sdyy = gy * gy * M0 - 2.f * gy * M2 + M5;
                     float4 o0, o1;
-                    o0.x = -ddelx_dx * (gco.x * Sdx + gco.y * Sdy);  // dL_dmean2D.x
-                    o0.y = -ddely_dy * (gco.z * Sdy + gco.y * Sdx);  // dL_dmean2D.y
-                    o0.z = -0.5f * Sdxx;                             // dL_dconic.x
-                    o0.w = -0.5f * Sdxy;                             // dL_dconic.y
-                    o1.x = -0.5f * Sdyy;                             // dL_dconic.w
-                    o1.y = M0 * __builtin_amdgcn_rcpf(gco.w);        // dL_dopacity = sum G dL_dalpha
+                    o0.x = -ddelx_dx * (ca * Sdx + cb * Sdy);  // dL_dmean2D.x
+                    o0.y = -ddely_dy * (cc * Sdy + cb * Sdx);  // dL_dmean2D.y
+                    o0.z = -0.5f * Sdxx;                       // dL_dconic.x
+                    o0.w = -0.5f * Sdxy;                       // dL_dconic.y
+                    o1.x = -0.5f * Sdyy;                       // dL_dconic.w
+                    o1.y = M0 * __builtin_amdgcn_rcpf(op);     // dL_dopacity = sum G dL_dalpha
                     o1.z = 0.f;
                     o1.w = 0.f;
                     reinterpret_cast<float4*>(my_mom + row * 8)[0] = o0;
@@ -321,12 +346,16 @@ __global__ void __launch_bounds__(256) blend_bwd32_mfma_kernel(
 #pragma unroll
                 for (int it = 0; it < 2; it++) {
                     const int row2 = 8 * it + (lane >> 3), f = lane & 7;
-                    const uint32_t gid2 = (uint32_t)__shfl((int)rid, row2, 64);
-                    if (((rowmask >> row2) & 1u) && f < 6) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * 8 + f]);
+                    const uint32_t gid2 = (uint32_t)__shfl(my_gid, row2, 64);
+                    if (((rowmask >> row2) & 1u) && f < 6 && !(ablate & 128)) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * 8 + f]);
                 }
             }
         }
     }
+    TK(4);
+    if (prof && lane == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(&gpack[8 * (i + 1) + 6], (float)tk[i]);
+#undef TK
 }
 
 }  // namespace mirast

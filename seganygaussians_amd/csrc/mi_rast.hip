@@ -536,6 +536,13 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
         else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
     }
+    if (g_ablate & 32) {
+        float dbg[48];
+        hipStreamSynchronize(stream);
+        hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mi_rast debug] bwd wave-cycles: head=%.3g dLstage=%.3g recstage=%.3g featstage+select=%.3g chunks+barrierwait=%.3g\n",
+                dbg[14], dbg[22], dbg[30], dbg[38], dbg[46]);
+    }
     STAGE_CHECK("render backward");
 
     const float* cov3D_ptr = (cov3D_precomp != nullptr) ? cov3D_precomp : geom.cov3D;  // rasterizer_impl.cu:411
