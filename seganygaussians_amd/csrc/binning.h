@@ -7,13 +7,13 @@
 // ranges[tile] -- is part of the bit-exact integer contract; the way to get there is not.
 //
 // MI355X design (produces the identical point_list / ranges):
-//   1. the per-Gaussian preprocess kernel also records every tile rect in a 2-D difference grid (4 atomics per
-//      Gaussian into a grid with one cell per 128-byte line; one atomic per overlap cost 0.22 ms at 12 M overlaps);
+//   1. the per-Gaussian preprocess kernel sums tiles_touched into R (what the host needs to size the binning buffer);
 //   2. ONE 32-bit radix sort of the P Gaussians by depth bits (stable, so ties keep index order) turns
 //      every visible Gaussian into a dense RANK in [0,V): ordering by rank == ordering by (depth, index);
-//   3. a single-workgroup kernel turns the grid into per-tile counts (2-D prefix in LDS) and scans them: ranges and R;
-//   4. rank emission: each (Gaussian, tile) overlap takes a slot tile_base[tile] + atomicAdd(cursor[tile])
-//      and stores the 4-byte RANK (arrival order inside a tile is arbitrary);
+//   3. a count pass over rank slices (per-tile counters in LDS), a scan over (tile, slice), and the scan of the tile
+//      totals give ranges[tile] and every slice's base inside every tile -- no global atomics;
+//   4. rank emission: each (Gaussian, tile) overlap takes its slot from an LDS cursor and stores the 4-byte RANK
+//      (arrival order inside a tile is arbitrary within a slice);
 //   5. per-tile LDS radix sort of the ranks (<= 24 significant bits, 8-bit digits, stable wave-match
 //      ranking), then point_list[slot] = sorted_idx[rank].
 // HBM traffic per overlap drops from ~172 B to ~16 B (4 B emit write, 4 B sort read, 4 B point_list
@@ -77,57 +77,28 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int l
     }
 }
 
-// ---- 3. per-tile counts from the 2-D difference grid, then their scan (single workgroup) -------------
-// The preprocess kernel adds +1/-1/-1/+1 at the four corners of every visible Gaussian's tile rect into a
-// (gy+1) x (gx+1) int grid (4 global atomics per Gaussian instead of one per overlap; a 2-D inclusive prefix sum
-// of that grid is exactly "how many rects cover tile (x,y)").  This kernel does the two prefix passes in LDS,
-// then the exclusive scan over tiles, and writes ranges[tile] = [base, base+count) (== identifyTileRanges'
-// result, rasterizer_impl.cu:116-138, including {0,0} for empty tiles as left by the reference's cudaMemset),
-// tile cursors = 0, and R.
-constexpr int SCAN_GRID_MAX = 36 * 1024;  // (gx+1)*(gy+1) ints that fit in LDS (covers 4K images at 16-px tiles)
-// In HBM every grid cell sits in its own 128-byte line: L2 atomics to ONE line serialise at ~22 ns each (measured:
-// 3.2 M corner atomics on a dense 33-KB grid took 0.28 ms), while distinct lines proceed in parallel.
-constexpr int GRID_STRIDE = 32;
+// ---- 3. tile ranges: exclusive scan of the per-tile totals (single workgroup) ------------------------------
+// Writes ranges[tile] = [base, base+count) (== identifyTileRanges' result, rasterizer_impl.cu:116-138, including
+// {0,0} for empty tiles as left by the reference's cudaMemset), R and the longest list.
+constexpr int BIN_MAX_WG = 512;        // workgroups of the count / emit passes (rank slices)
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_MAX_TILES = 36 * 1024;  // LDS: one counter per tile (covers 4K images at 16-px tiles)
 
-__global__ void __launch_bounds__(1024) tile_scan_kernel(int gx, int gy, const int* __restrict__ diff_grid,
-                                                         uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
-                                                         int* __restrict__ num_rendered)
+__global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_total,
+                                                           uint2* __restrict__ ranges, int* __restrict__ num_rendered)
 {
-    extern __shared__ int s_grid[];  // (gy+1) x (gx+1)
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_maxcount;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gw = gx + 1, gh = gy + 1, ntiles = gx * gy;
-    if (tid == 0) s_maxcount = 0;
-    for (int i = tid; i < gw * gh; i += 1024) s_grid[i] = diff_grid[(size_t)i * GRID_STRIDE];
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    // row-wise inclusive prefix: one wave per row
-    for (int y = wave; y < gh; y += 16) {
-        uint32_t carry = 0;
-        for (int x0 = 0; x0 < gw; x0 += 64) {
-            const int x = x0 + lane;
-            const uint32_t v = x < gw ? (uint32_t)s_grid[y * gw + x] : 0u;
-            const uint32_t incl = wave_inclusive_scan(v, lane) + carry;
-            if (x < gw) s_grid[y * gw + x] = (int)incl;
-            carry = __shfl(incl, 63, 64);
-        }
+    if (tid == 0) {
+        s_maxcount = 0;
+        s_carry = 0;
     }
     __syncthreads();
-    // column-wise inclusive prefix: one thread per column (consecutive threads -> consecutive banks)
-    for (int x = tid; x < gw; x += 1024) {
-        int run = 0;
-        for (int y = 0; y < gh; y++) {
-            run += s_grid[y * gw + x];
-            s_grid[y * gw + x] = run;
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the counts over tiles (tile = y * gx + x)
     for (int base = 0; base < ntiles; base += 1024) {
         const int t = base + tid;
-        const uint32_t c = t < ntiles ? (uint32_t)s_grid[(t / gx) * gw + (t % gx)] : 0u;
+        const uint32_t c = t < ntiles ? tile_total[t] : 0u;
         const uint32_t incl = wave_inclusive_scan(c, lane);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
@@ -135,10 +106,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int gx, int gy, const i
         for (int w = 0; w < wave; w++) woff += s_wave[w];
         const uint32_t carry = s_carry;
         const uint32_t excl = carry + woff + incl - c;
-        if (t < ntiles) {
-            ranges[t] = c ? make_uint2(excl, excl + c) : make_uint2(0u, 0u);
-            tile_cursor[t] = 0u;
-        }
+        if (t < ntiles) ranges[t] = c ? make_uint2(excl, excl + c) : make_uint2(0u, 0u);
         {
             uint32_t m = c;
 #pragma unroll
@@ -150,8 +118,8 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int gx, int gy, const i
         __syncthreads();
     }
     if (tid == 0) {
-        num_rendered[0] = (int)s_carry;       // R
-        num_rendered[1] = (int)s_maxcount;    // longest tile list: lets the host skip unused sort size classes
+        num_rendered[0] = (int)s_carry;     // R (the host already has it from the preprocess pass; kept for checks)
+        num_rendered[1] = (int)s_maxcount;  // longest tile list
     }
 }
 
@@ -194,36 +162,94 @@ __global__ void __launch_bounds__(256) build_rank_records_kernel(int P, const ui
     rank_rec[r] = rec;
 }
 
-// ---- 4. rank emission ------------------------------------------------------------------------------
-// Thread r handles the Gaussian of depth rank r (sorted_idx[r]); ranks >= V map to culled Gaussians.  One global
-// returning atomic per overlap: lanes walking a rect row hit consecutive cursors, which the L2 handles as one line
-// operation.  (Tried and rejected: privatising the cursors in LDS with persistent workgroups -- the per-(workgroup,
-// tile) reservation atomics and the two LDS-atomic walks made it 2x slower, 0.51 ms vs 0.24 ms.)
-__global__ void __launch_bounds__(256) emit_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
-                                                         const uint2* __restrict__ ranges,
-                                                         uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ entries,
-                                                         uint32_t gx, uint32_t gy)
+// ---- 4. counting and rank emission -------------------------------------------------------------------
+// Global atomics are the scarce resource of the binning stages (about 25 G scattered dword atomics/s on this part:
+// one corner atomic per Gaussian and one cursor atomic per overlap were 0.11 + 0.27 ms per view).  So the bucketing
+// is done the way a radix-sort pass does it.  The depth ranks are dealt to <= 512 workgroups of 1024 threads in
+// blocks of 1024 ranks, round robin (near Gaussians cover hundreds of tiles, far ones one or two: contiguous rank
+// slices would be badly unbalanced); the set of ranks a workgroup owns is its "slice":
+//   count pass  (EMIT = false): per-tile counters in LDS, one LDS atomic per overlap; the counters go to
+//                partial[slice][tile] with plain stores;
+//   scan        (scan_partials_kernel): per tile, the exclusive prefix over slices (in place) and the tile total;
+//   emit pass   (EMIT = true): LDS cursors start at ranges[tile].x + partial[slice][tile]; every overlap takes
+//                its slot with a returning LDS atomic and stores its 4-byte depth rank.
+// Both passes enumerate the overlaps with the same code, so the counts cannot disagree with the emission.  Inside a
+// tile the entries of one slice arrive in arbitrary order; the per-tile sort below does not care.
+inline int bin_workgroups(int P)
 {
-    __shared__ uint32_t s_prefix[4][64], s_rx[4][64], s_ry[4][64];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
-    uint32_t count = 0;
-    if (r < P) {
-        const BlendRec rec = rank_rec[r];
-        const int rad = (int)rec.pm;
-        if (rad > 0) {
-            getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
-            count = (rmax.x - rmin.x) * (rmax.y - rmin.y);
+    const int blocks = (P + BIN_THREADS - 1) / BIN_THREADS;
+    return blocks < 1 ? 1 : (blocks > BIN_MAX_WG ? BIN_MAX_WG : blocks);
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
+                                                                uint32_t* __restrict__ partial,
+                                                                const uint2* __restrict__ ranges,
+                                                                uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy)
+{
+    extern __shared__ uint32_t s_dyn[];  // [ntiles] counters / cursors, then 16 x 3 x 64 words of rect hand-off
+    const int ntiles = (int)(gx * gy);
+    uint32_t* s_cnt = s_dyn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* s_rw = s_dyn + ntiles + wave * 192;
+    uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles;
+    for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = EMIT ? ranges[t].x + my_partial[t] : 0u;
+    __syncthreads();
+    RectWork rw{s_rw, s_rw + 64, s_rw + 128};
+    for (int base = blockIdx.x * BIN_THREADS; base < P; base += gridDim.x * BIN_THREADS) {
+        const int r = base + tid;
+        uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
+        uint32_t count = 0;
+        if (r < P) {
+            const BlendRec rec = rank_rec[r];
+            const int rad = (int)rec.pm;
+            if (rad > 0) {
+                getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
+                count = (rmax.x - rmin.x) * (rmax.y - rmin.y);
+            }
         }
+        if (ballot64(count != 0) == 0) continue;  // wave-uniform
+        const uint32_t rank0 = (uint32_t)(r - lane);
+        for_each_tile_balanced(rw, lane, rmin, rmax, count, gx, [&](uint32_t owner_lane, uint32_t tile) {
+            if (EMIT) {
+                const uint32_t slot = atomicAdd(&s_cnt[tile], 1u);
+                entries[slot] = rank0 + owner_lane;
+            } else {
+                atomicAdd(&s_cnt[tile], 1u);
+            }
+        });
     }
-    if (ballot64(count != 0) == 0) return;
-    RectWork rw{s_prefix[wave], s_rx[wave], s_ry[wave]};
-    const uint32_t rank0 = (uint32_t)(r - lane);
-    for_each_tile_balanced(rw, lane, rmin, rmax, count, gx, [&](uint32_t owner_lane, uint32_t tile) {
-        const uint32_t slot = ranges[tile].x + atomicAdd(&tile_cursor[tile], 1u);
-        entries[slot] = rank0 + owner_lane;
-    });
+    if (!EMIT) {
+        __syncthreads();
+        for (int t = tid; t < ntiles; t += BIN_THREADS) my_partial[t] = s_cnt[t];
+    }
+}
+
+// Per tile: exclusive prefix of partial[slice][tile] over the slices (in place) and tile_total[tile].
+// One workgroup handles 64 tiles x 16 groups of slices; every load is coalesced along the tile axis.
+__global__ void __launch_bounds__(1024) scan_partials_kernel(int ntiles, int nwg, uint32_t* __restrict__ partial,
+                                                             uint32_t* __restrict__ tile_total)
+{
+    __shared__ uint32_t s_sum[16][64];
+    const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    const int wpg = (nwg + 15) / 16;
+    const int w0 = g * wpg, w1 = min(nwg, w0 + wpg);
+    uint32_t sum = 0;
+    if (t < ntiles)
+        for (int w = w0; w < w1; w++) sum += partial[(size_t)w * ntiles + t];
+    s_sum[g][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int gg = 0; gg < g; gg++) run += s_sum[gg][tl];
+    if (t < ntiles) {
+        for (int w = w0; w < w1; w++) {
+            const uint32_t c = partial[(size_t)w * ntiles + t];
+            partial[(size_t)w * ntiles + t] = run;
+            run += c;
+        }
+        if (g == 15) tile_total[t] = run;
+    }
 }
 
 // ---- 5. per-tile LDS radix sort of the ranks --------------------------------------------------------

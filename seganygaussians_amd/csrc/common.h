@@ -13,6 +13,10 @@
 
 namespace mirast {
 
+constexpr int R_SLOTS = 64;        // partial sums of R, one per 128-byte line
+constexpr int R_SLOT_STRIDE = 32;  // ints
+
+
 constexpr int TILE_X = 16;  // CF/cuda_rasterizer/config_contrastive_f.h:16 -- part of the integer contract
 constexpr int TILE_Y = 16;  // CF/cuda_rasterizer/config_contrastive_f.h:17
 constexpr int TILE_PIXELS = TILE_X * TILE_Y;

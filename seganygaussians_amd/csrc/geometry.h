@@ -114,8 +114,7 @@ __device__ __forceinline__ float3 computeColorFromSH(int idx, int deg, int max_c
 // `culled_prefiltered` is incremented when prefiltered is set and a point is culled (the reference
 // printf+__trap()s the whole context there; we report an error instead).
 // gfx950 additions (binning.h): writes the 32-bit depth sort key (0xFFFFFFFF for culled Gaussians) and the
-// identity index array for the depth sort, and records the tile rect in the 2-D difference grid that
-// tile_scan_kernel integrates into per-tile counts.
+// identity index array for the depth sort, and accumulates R = sum of tiles_touched of the visible Gaussians.
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -123,7 +122,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int* __restrict__ radii, float2* __restrict__ points_xy_image, float* __restrict__ depths,
     float* __restrict__ cov3Ds, float* __restrict__ rgb, float4* __restrict__ conic_opacity,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ idx_iota,
-    int* __restrict__ diff_grid, int prefiltered, int* __restrict__ culled_prefiltered)
+    int* __restrict__ r_slots, int prefiltered, int* __restrict__ culled_prefiltered)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     int my_radii = 0;
@@ -193,13 +192,14 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         depth_key[idx] = my_key;
         idx_iota[idx] = (uint32_t)idx;
     }
-    // tile-overlap histogram as a 2-D difference grid ((grid_y+1) x (grid_x+1), one cell per 128-B line)
-    if ((rect_max.x - rect_min.x) * (rect_max.y - rect_min.y) != 0) {
-        const int gw = (int)vp.grid_x + 1;
-        atomicAdd(&diff_grid[(size_t)(rect_min.y * gw + rect_min.x) * GRID_STRIDE], 1);
-        atomicAdd(&diff_grid[(size_t)(rect_min.y * gw + rect_max.x) * GRID_STRIDE], -1);
-        atomicAdd(&diff_grid[(size_t)(rect_max.y * gw + rect_min.x) * GRID_STRIDE], -1);
-        atomicAdd(&diff_grid[(size_t)(rect_max.y * gw + rect_max.x) * GRID_STRIDE], 1);
+    // R = sum of tiles_touched over the Gaussians that later stages treat as visible (what InclusiveSum's last
+    // element is in the reference, rasterizer_impl.cu:277-281).  One atomic per wave, spread over R_SLOTS lines:
+    // same-line L2 atomics serialise at ~22 ns each.
+    {
+        uint32_t sum = (rect_max.x - rect_min.x) * (rect_max.y - rect_min.y);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+        if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&r_slots[(blockIdx.x % R_SLOTS) * R_SLOT_STRIDE], (int)sum);
     }
 }
 

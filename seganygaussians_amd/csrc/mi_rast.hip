@@ -70,14 +70,16 @@ size_t depth_sort_temp_bytes(int P)
 
 // ---- host-side scratch for the num_rendered read-back: pinned word + event, one per host thread -------
 struct HostSync {
-    int* pinned = nullptr;
+    int* pinned = nullptr;   // R partial sums, then {R, longest tile list} of the range scan
     hipEvent_t ev = nullptr;
+    hipEvent_t ev2 = nullptr;
     bool ok = false;
     bool init()
     {
         if (ok) return true;
-        if (hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&pinned, (R_SLOTS * R_SLOT_STRIDE + 4) * sizeof(int), hipHostMallocDefault) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess) return false;
         ok = true;
         return true;
     }
@@ -239,17 +241,16 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     int* cull_counter = (int*)geom.sort_temp;
     if (prefiltered) HIP_TRY(hipMemsetAsync(cull_counter, 0, sizeof(int), stream));
     const int ntiles = (int)(vp.grid_x * vp.grid_y);
-    const size_t grid_cells = (size_t)(vp.grid_x + 1) * (vp.grid_y + 1);
-    if (grid_cells > (size_t)SCAN_GRID_MAX)
-        return fail(MI_RAST_ERR_INVALID, "image too large: more than 36K tile-grid cells (about 4800 x 1900 px at 16-px tiles)");
+    if (ntiles > BIN_MAX_TILES)
+        return fail(MI_RAST_ERR_INVALID, "image too large: more than 36K tiles (about 4800 x 1900 px at 16-px tiles)");
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
-        HIP_TRY(hipMemsetAsync(img.tile_count, 0, grid_cells * GRID_STRIDE * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(img.num_rendered, 0, R_SLOTS * R_SLOT_STRIDE * sizeof(int), stream));
         HIP_TRY(hipMemsetAsync(img.blend_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
-                           geom.depth_key, geom.idx_iota, (int*)img.tile_count, prefiltered, cull_counter);
+                           geom.depth_key, geom.idx_iota, img.num_rendered, prefiltered, cull_counter);
     }
     STAGE_CHECK("preprocess");
     if (prefiltered) {
@@ -259,24 +260,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         if (culled)
             return fail(MI_RAST_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");
     }
-    {
-        // tile scan first: it only needs tile_count, and its result (R) is what the host waits for; the depth
-        // sort of the Gaussians is queued behind it and overlaps the host round trip + buffer allocation.
-        StageTimer t(stream, MI_STAGE_TILE_SCAN);
-        if (grid_cells * sizeof(int) > 48 * 1024) {
-            static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
-            if (!attr_set) {
-                HIP_TRY(hipFuncSetAttribute((const void*)tile_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            SCAN_GRID_MAX * (int)sizeof(int)));
-                attr_set = true;
-            }
-        }
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), grid_cells * sizeof(int), stream, (int)vp.grid_x,
-                           (int)vp.grid_y, (const int*)img.tile_count, img.ranges, img.tile_cursor, img.num_rendered);
-    }
-    STAGE_CHECK("tile scan");
-    if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host word / event");
-    HIP_TRY(hipMemcpyAsync(g_host_sync.pinned, img.num_rendered, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    // R is known after the preprocess pass; its copy to the host overlaps the depth sort and the counting passes.
+    if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host buffer / event");
+    HIP_TRY(hipMemcpyAsync(g_host_sync.pinned, img.num_rendered, R_SLOTS * R_SLOT_STRIDE * sizeof(int),
+                           hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
     {
         StageTimer t(stream, MI_STAGE_DEPTH_SORT);
@@ -286,11 +273,38 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                            geom.means2D, geom.conic_opacity, radii, geom.rank_rec);
     }
     STAGE_CHECK("depth sort");
+    const int nwg = bin_workgroups(P);
+    const size_t bin_lds = ((size_t)ntiles + 16 * 192) * sizeof(uint32_t);
+    {
+        static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
+        if (!attr_set) {
+            const int max_lds = (int)((BIN_MAX_TILES + 16 * 192) * sizeof(uint32_t));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            attr_set = true;
+        }
+    }
+    {
+        // count pass over rank slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
+        StageTimer t(stream, MI_STAGE_TILE_SCAN);
+        hipLaunchKernelGGL(bin_ranks_kernel<false>, dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+                           img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
+        hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
+                           img.tile_count, img.tile_cursor);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, stream, ntiles, img.tile_cursor, img.ranges,
+                           img.num_rendered + R_SLOTS * R_SLOT_STRIDE);
+    }
+    STAGE_CHECK("tile scan");
+    HIP_TRY(hipMemcpyAsync(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE, img.num_rendered + R_SLOTS * R_SLOT_STRIDE,
+                           2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(g_host_sync.ev2, stream));
     // rasterizer_impl.cu:280-281: the host needs num_rendered to size the binning buffer.  We wait only for
-    // the copy (event), not for the depth sort queued behind it.
+    // the copy (event), not for the work queued behind it.
     HIP_TRY(hipEventSynchronize(g_host_sync.ev));
-    const int R = g_host_sync.pinned[0];
-    const int max_tile_count = g_host_sync.pinned[1];
+    long long Rsum = 0;
+    for (int k = 0; k < R_SLOTS; k++) Rsum += g_host_sync.pinned[k * R_SLOT_STRIDE];
+    if (Rsum > 0x7fffffffll) return fail(MI_RAST_ERR_INVALID, "more than 2^31 tile overlaps");
+    const int R = (int)Rsum;
     *num_rendered = R;
 
     size_t boff[MI_BIN_NFIELDS];
@@ -301,8 +315,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            hipLaunchKernelGGL(emit_ranks_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.rank_rec,
-                               img.ranges, img.tile_cursor, bin.entries, vp.grid_x, vp.grid_y);
+            hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+                               img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
         }
         STAGE_CHECK("emit ranks");
         int rank_bits = 1;
@@ -311,11 +325,16 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         if (g_ablate_fwd & 256) passes = 0;  // timing experiment: skip the radix passes (wrong order)
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
-            // three list-length classes (LDS footprint 20 / 52 / 100 KB per workgroup); a class is launched only
-            // if some tile needs it (the scan kernel reports the longest list together with R)
+            // three list-length classes (LDS footprint 20 / 52 / 100 KB per workgroup); a class is launched only if
+            // some tile needs it.  The longest list was copied to the host right after the range scan, which
+            // finished before the emit pass above even started: this wait does not stall the queue.
             hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
                                bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
                                img.blend_count, vp.grid_x);
+            HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
+            if (g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R)
+                return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
+            const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
             if (max_tile_count > 2048)
                 hipLaunchKernelGGL((tile_sort_kernel<2048, 6144, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
                                    bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
@@ -407,10 +426,10 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     off[MI_IMG_N_CONTRIB] = c.take(n * sizeof(uint32_t));
     off[MI_IMG_RANGES] = c.take((tiles ? tiles : 1) * sizeof(uint2));
     off[MI_IMG_TILE_CONSUMED] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
-    // tile_count holds the (gy+1) x (gx+1) difference grid of the tile-overlap histogram, one cell per 128-B line
-    off[MI_IMG_TILE_COUNT] = c.take((size_t)((width + TILE_X - 1) / TILE_X + 1) * ((height + TILE_Y - 1) / TILE_Y + 1) * GRID_STRIDE * sizeof(int));
+    // tile_count holds partial[slice][tile] of the count / emit passes (binning.h); tile_cursor the tile totals
+    off[MI_IMG_TILE_COUNT] = c.take((size_t)BIN_MAX_WG * (tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
-    off[MI_IMG_NUM_RENDERED] = c.take(16);
+    off[MI_IMG_NUM_RENDERED] = c.take((R_SLOTS * R_SLOT_STRIDE + 4) * sizeof(int));  // R partial sums, then {R, longest list}
     off[MI_IMG_BLEND_COUNT] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_NSURV] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     return c.off;
@@ -538,8 +557,8 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     }
     if (g_ablate & 32) {
         float dbg[48];
-        hipStreamSynchronize(stream);
-        hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);
         fprintf(stderr, "[mi_rast debug] bwd wave-cycles: head=%.3g dLstage=%.3g recstage=%.3g featstage+select=%.3g chunks+barrierwait=%.3g\n",
                 dbg[14], dbg[22], dbg[30], dbg[38], dbg[46]);
     }
