@@ -25,16 +25,12 @@
 
 namespace mirast {
 
-// ---- wave-balanced enumeration of tile rects ---------------------------------------------------
-// Each lane owns one Gaussian with `count` tiles (0 if culled) in rect [rmin, rmax).  The wave walks the
-// concatenation of all 64 rects with every lane busy: item k belongs to the lane whose inclusive prefix
-// first exceeds k (binary search in an LDS copy of the prefix), and its tile follows from k's offset.
-struct RectWork {
-    uint32_t* prefix;  // LDS [64] inclusive prefix of counts   (per wave)
-    uint32_t* rx;      // LDS [64] rect_min.x | width << 16      (per wave)
-    uint32_t* ry;      // LDS [64] rect_min.y
-};
-
+// ---- workgroup-balanced enumeration of tile rects -------------------------------------------------------
+// Each of the 1024 threads owns one Gaussian with `count` tiles (0 if culled) in rect [rmin, rmax).  Tile counts
+// are extremely skewed along the depth-rank axis (BASELINE cfg3: median 6 tiles, 99.9th percentile 484, maximum
+// 4056; the heaviest 64 consecutive ranks hold 12x the average), so the WORKGROUP walks the concatenation of all
+// 1024 rects with every thread busy: item k belongs to the thread whose inclusive prefix first exceeds k (binary
+// search in an LDS copy of the prefix), and its tile follows from k's offset inside that rect.
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
 {
 #pragma unroll
@@ -45,29 +41,43 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
     return v;
 }
 
+struct RectWork {
+    uint32_t* prefix;  // LDS [1024] inclusive prefix of counts
+    uint32_t* rx;      // LDS [1024] rect_min.x | width << 16
+    uint32_t* ry;      // LDS [1024] rect_min.y
+    uint32_t* wsum;    // LDS [16]
+};
+
+// Contains workgroup barriers: call from all 1024 threads.  f(owner_thread, tile).
 template <typename F>
-__device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int lane, uint2 rmin, uint2 rmax, uint32_t count,
+__device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int tid, uint2 rmin, uint2 rmax, uint32_t count,
                                                        uint32_t gx, F&& f)
 {
-    const uint32_t incl = wave_inclusive_scan(count, lane);
-    const uint32_t width = rmax.x - rmin.x;
-    rw.prefix[lane] = incl;
-    rw.rx[lane] = rmin.x | (width << 16);
-    rw.ry[lane] = rmin.y;
-    const uint32_t total = __shfl(incl, 63, 64);
-    // wave-local LDS hand-off (same wave writes then reads; DS ops of one wave execute in order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (uint32_t k = lane; k < total; k += 64) {
-        // first lane o with prefix[o] > k
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = wave_inclusive_scan(count, lane);
+    if (lane == 63) rw.wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t c = rw.wsum[w];
+        woff += w < wave ? c : 0u;
+        total += c;
+    }
+    incl += woff;
+    rw.prefix[tid] = incl;
+    rw.rx[tid] = rmin.x | ((rmax.x - rmin.x) << 16);
+    rw.ry[tid] = rmin.y;
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += 1024) {
+        // first thread o with prefix[o] > k
         int lo = 0;
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1)
+        for (int step = 512; step >= 1; step >>= 1)
             if (rw.prefix[lo + step - 1] <= k) lo += step;
-        const uint32_t owner_incl = rw.prefix[lo];
         const uint32_t packed = rw.rx[lo];
         const uint32_t w = packed >> 16, x0 = packed & 0xFFFFu, y0 = rw.ry[lo];
         const uint32_t prev = lo == 0 ? 0u : rw.prefix[lo - 1];
-        (void)owner_incl;
         const uint32_t i = k - prev;
         // row = i / w without an integer divide: (i + 0.5) / w is never within float error of an integer
         // boundary for i < 2^14 * w (a Gaussian covers at most grid_x * grid_y tiles)
@@ -75,6 +85,7 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int l
         const uint32_t col = i - row * w;
         f((uint32_t)lo, (y0 + row) * gx + x0 + col);
     }
+    __syncthreads();  // LDS hand-off arrays are reused by the next call
 }
 
 // ---- 3. tile ranges: exclusive scan of the per-tile totals (single workgroup) ------------------------------
@@ -166,8 +177,7 @@ __global__ void __launch_bounds__(256) build_rank_records_kernel(int P, const ui
 // Global atomics are the scarce resource of the binning stages (about 25 G scattered dword atomics/s on this part:
 // one corner atomic per Gaussian and one cursor atomic per overlap were 0.11 + 0.27 ms per view).  So the bucketing
 // is done the way a radix-sort pass does it.  The depth ranks are dealt to <= 512 workgroups of 1024 threads in
-// blocks of 1024 ranks, round robin (near Gaussians cover hundreds of tiles, far ones one or two: contiguous rank
-// slices would be badly unbalanced); the set of ranks a workgroup owns is its "slice":
+// chunks of 64 ranks, round robin; the set of ranks a workgroup owns is its "slice":
 //   count pass  (EMIT = false): per-tile counters in LDS, one LDS atomic per overlap; the counters go to
 //                partial[slice][tile] with plain stores;
 //   scan        (scan_partials_kernel): per tile, the exclusive prefix over slices (in place) and the tile total;
@@ -187,17 +197,21 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
                                                                 const uint2* __restrict__ ranges,
                                                                 uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy)
 {
-    extern __shared__ uint32_t s_dyn[];  // [ntiles] counters / cursors, then 16 x 3 x 64 words of rect hand-off
+    extern __shared__ uint32_t s_dyn[];  // [ntiles] counters / cursors, then the rect hand-off arrays
     const int ntiles = (int)(gx * gy);
     uint32_t* s_cnt = s_dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t* s_rw = s_dyn + ntiles + wave * 192;
+    uint32_t* s_rw = s_dyn + ntiles;
+    RectWork rw{s_rw, s_rw + 1024, s_rw + 2048, s_rw + 3072};
     uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles;
     for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = EMIT ? ranges[t].x + my_partial[t] : 0u;
     __syncthreads();
-    RectWork rw{s_rw, s_rw + 64, s_rw + 128};
-    for (int base = blockIdx.x * BIN_THREADS; base < P; base += gridDim.x * BIN_THREADS) {
-        const int r = base + tid;
+    // 64-rank chunks are dealt round robin over all the waves of all the workgroups: chunk c belongs to workgroup
+    // c % nwg, wave slot (c / nwg) % 16, round (c / nwg) / 16 -- the heavy (near) chunks end up in different workgroups
+    const int nwg = (int)gridDim.x;
+    const int rounds = ((P + 63) / 64 + 16 * nwg - 1) / (16 * nwg);
+    for (int it = 0; it < rounds; it++) {
+        const int r = ((it * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane;
         uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
         uint32_t count = 0;
         if (r < P) {
@@ -208,12 +222,10 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
                 count = (rmax.x - rmin.x) * (rmax.y - rmin.y);
             }
         }
-        if (ballot64(count != 0) == 0) continue;  // wave-uniform
-        const uint32_t rank0 = (uint32_t)(r - lane);
-        for_each_tile_balanced(rw, lane, rmin, rmax, count, gx, [&](uint32_t owner_lane, uint32_t tile) {
+        for_each_tile_balanced(rw, tid, rmin, rmax, count, gx, [&](uint32_t owner, uint32_t tile) {
             if (EMIT) {
                 const uint32_t slot = atomicAdd(&s_cnt[tile], 1u);
-                entries[slot] = rank0 + owner_lane;
+                entries[slot] = (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
             } else {
                 atomicAdd(&s_cnt[tile], 1u);
             }

@@ -274,11 +274,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     }
     STAGE_CHECK("depth sort");
     const int nwg = bin_workgroups(P);
-    const size_t bin_lds = ((size_t)ntiles + 16 * 192) * sizeof(uint32_t);
+    const size_t bin_lds = ((size_t)ntiles + 3 * 1024 + 16) * sizeof(uint32_t);
     {
         static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
         if (!attr_set) {
-            const int max_lds = (int)((BIN_MAX_TILES + 16 * 192) * sizeof(uint32_t));
+            const int max_lds = (int)((BIN_MAX_TILES + 3 * 1024 + 16) * sizeof(uint32_t));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             attr_set = true;
