@@ -48,7 +48,7 @@ struct RectWork {
     uint32_t* wsum;    // LDS [16]
 };
 
-// Contains workgroup barriers: call from all 1024 threads.  f(owner_thread, tile).
+// Contains workgroup barriers: call from all 1024 threads.  f(owner_thread, tile_x, tile_y).
 template <typename F>
 __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int tid, uint2 rmin, uint2 rmax, uint32_t count,
                                                        uint32_t gx, F&& f)
@@ -83,7 +83,7 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
         // boundary for i < 2^14 * w (a Gaussian covers at most grid_x * grid_y tiles)
         const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w));
         const uint32_t col = i - row * w;
-        f((uint32_t)lo, (y0 + row) * gx + x0 + col);
+        f((uint32_t)lo, x0 + col, y0 + row);
     }
     __syncthreads();  // LDS hand-off arrays are reused by the next call
 }
@@ -91,9 +91,11 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
 // ---- 3. tile ranges: exclusive scan of the per-tile totals (single workgroup) ------------------------------
 // Writes ranges[tile] = [base, base+count) (== identifyTileRanges' result, rasterizer_impl.cu:116-138, including
 // {0,0} for empty tiles as left by the reference's cudaMemset), R and the longest list.
+constexpr int RANK_BITS = 28;          // entry = depth rank | quadrant mask << 28
+constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 constexpr int BIN_MAX_WG = 512;        // workgroups of the count / emit passes (rank slices)
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_TILES = 36 * 1024;  // LDS: one counter per tile (covers 4K images at 16-px tiles)
+constexpr int BIN_MAX_TILES = 31 * 1024 - 64;  // LDS: one counter per tile + 37 KB of hand-off arrays must fit in 160 KB
 
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered)
@@ -201,8 +203,10 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
     const int ntiles = (int)(gx * gy);
     uint32_t* s_cnt = s_dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t* s_rw = s_dyn + ntiles;
+    uint32_t* s_rw = s_dyn + ((ntiles + 3) & ~3);  // 16-byte aligned
     RectWork rw{s_rw, s_rw + 1024, s_rw + 2048, s_rw + 3072};
+    float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);          // EMIT only: the owners' means ...
+    float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);   // ... and conics + opacities
     uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles;
     for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = EMIT ? ranges[t].x + my_partial[t] : 0u;
     __syncthreads();
@@ -221,11 +225,20 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
                 getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
                 count = (rmax.x - rmin.x) * (rmax.y - rmin.y);
             }
-        }
-        for_each_tile_balanced(rw, tid, rmin, rmax, count, gx, [&](uint32_t owner, uint32_t tile) {
             if (EMIT) {
+                s_xy[tid] = rec.xy;
+                s_co[tid] = rec.co;
+            }
+        }
+        for_each_tile_balanced(rw, tid, rmin, rmax, count, gx, [&](uint32_t owner, uint32_t tx, uint32_t ty) {
+            const uint32_t tile = ty * gx + tx;
+            if (EMIT) {
+                // the exact-conservative cull (cull.h) is evaluated here, where the record is at hand, and rides in
+                // the top 4 bits of the entry: the per-tile sort then gathers a record only for entries that blend
+                const uint32_t qmask = quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
+                const uint32_t rank = (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
                 const uint32_t slot = atomicAdd(&s_cnt[tile], 1u);
-                entries[slot] = (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
+                entries[slot] = rank | (qmask << RANK_BITS);
             } else {
                 atomicAdd(&s_cnt[tile], 1u);
             }
@@ -297,7 +310,7 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
         const int i = i0 + lane;
         const bool active = i < end;
         const uint32_t key = active ? (uint32_t)src[i] : 0u;
-        const uint32_t digit = (key >> shift) & 0xFFu;
+        const uint32_t digit = ((key & RANK_MASK) >> shift) & 0xFFu;
         uint32_t rk, cnt;
         match(digit, active, rk, cnt);
         if (active && rk == 0) s_hist[wave][digit] += cnt;  // one lane per distinct digit, wave-private row
@@ -326,7 +339,7 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
         const int i = i0 + lane;
         const bool active = i < end;
         const uint32_t key = active ? (uint32_t)src[i] : 0u;
-        const uint32_t digit = (key >> shift) & 0xFFu;
+        const uint32_t digit = ((key & RANK_MASK) >> shift) & 0xFFu;
         uint32_t rk, cnt;
         match(digit, active, rk, cnt);
         uint32_t off = 0;
@@ -341,40 +354,33 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
 // Emits point_list (the reference-exact sorted id list) and, in the same pass, the compacted blend list of the
 // tile: entries whose quadrant mask is non-zero, in list order, at blend_rec[range.x ...], count in blend_count.
 template <typename SrcPtr>
-__device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_ranks, int n, uint2 range, int tid,
+__device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, int n, uint2 range, int tid,
+                                                const uint32_t* __restrict__ sorted_idx,
                                                 const BlendRec* __restrict__ rank_rec,
                                                 uint32_t* __restrict__ point_list, BlendRec* __restrict__ blend_rec,
-                                                uint32_t* __restrict__ blend_count, uint32_t tile, uint32_t gx,
-                                                uint32_t* s_wcount)
+                                                uint32_t* __restrict__ blend_count, uint32_t tile, uint32_t* s_wcount)
 {
     const int wave = tid >> 6;
-    const float tile_px = (float)((tile % gx) * TILE_X), tile_py = (float)((tile / gx) * TILE_Y);
     uint32_t* out = point_list + range.x;
     BlendRec* rec = blend_rec + range.x;
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
-        uint32_t g = 0, qmask = 0;
-        float2 xy = make_float2(0.f, 0.f);
-        float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t qmask = 0;
+        BlendRec r;
         if (i < n) {
-            const BlendRec rr = rank_rec[sorted_ranks[i]];
-            g = rr.id;
-            out[i] = g;
-            xy = rr.xy;
-            co = rr.co;
-            qmask = quadrant_mask(xy, co, tile_px, tile_py);
+            const uint32_t e = sorted_entries[i];
+            const uint32_t rank = e & RANK_MASK;
+            qmask = e >> RANK_BITS;
+            out[i] = sorted_idx[rank];
+            if (qmask) {
+                r = rank_rec[rank];
+                r.pm = ((uint32_t)i << 4) | qmask;
+            }
         }
         int ns;
         const int slot = compact_slot(qmask != 0, wave, s_wcount, ns);
-        if (slot >= 0) {
-            BlendRec r;
-            r.xy = xy;
-            r.id = g;
-            r.pm = ((uint32_t)i << 4) | qmask;
-            r.co = co;
-            rec[base + slot] = r;
-        }
+        if (slot >= 0) rec[base + slot] = r;
         base += ns;
         __syncthreads();  // s_wcount reuse
     }
@@ -384,10 +390,11 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_ranks, int n, uint
 template <int LO, int CAP, bool GLOBAL_FALLBACK>
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ entries,
                                                         uint32_t* __restrict__ scratch,
+                                                        const uint32_t* __restrict__ sorted_idx,
                                                         const BlendRec* __restrict__ rank_rec,
                                                         uint32_t* __restrict__ point_list, int passes,
                                                         BlendRec* __restrict__ blend_rec,
-                                                        uint32_t* __restrict__ blend_count, uint32_t gx)
+                                                        uint32_t* __restrict__ blend_count)
 {
     __shared__ uint32_t s_a[CAP];
     __shared__ uint32_t s_b[CAP];
@@ -411,7 +418,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
             a = b;
             b = t;
         }
-        emit_tile_lists(a, n, range, tid, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, gx, s_wcount);
+        emit_tile_lists(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
@@ -421,7 +428,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
             a = b;
             b = t;
         }
-        emit_tile_lists(a, n, range, tid, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, gx, s_wcount);
+        emit_tile_lists(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
     }
 }
 

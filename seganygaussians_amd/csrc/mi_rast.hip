@@ -241,8 +241,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     int* cull_counter = (int*)geom.sort_temp;
     if (prefiltered) HIP_TRY(hipMemsetAsync(cull_counter, 0, sizeof(int), stream));
     const int ntiles = (int)(vp.grid_x * vp.grid_y);
+    if (P >= (1 << RANK_BITS)) return fail(MI_RAST_ERR_INVALID, "more than 2^28 Gaussians");
     if (ntiles > BIN_MAX_TILES)
-        return fail(MI_RAST_ERR_INVALID, "image too large: more than 36K tiles (about 4800 x 1900 px at 16-px tiles)");
+        return fail(MI_RAST_ERR_INVALID, "image too large: more than 31680 tiles (e.g. 3840 x 2112 px at 16-px tiles)");
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
         HIP_TRY(hipMemsetAsync(img.num_rendered, 0, R_SLOTS * R_SLOT_STRIDE * sizeof(int), stream));
@@ -274,11 +275,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     }
     STAGE_CHECK("depth sort");
     const int nwg = bin_workgroups(P);
-    const size_t bin_lds = ((size_t)ntiles + 3 * 1024 + 16) * sizeof(uint32_t);
+    const size_t bin_lds = ((size_t)((ntiles + 3) & ~3) + 3 * 1024 + 16) * sizeof(uint32_t);
     {
         static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
         if (!attr_set) {
-            const int max_lds = (int)((BIN_MAX_TILES + 3 * 1024 + 16) * sizeof(uint32_t));
+            const int max_lds = (int)((BIN_MAX_TILES + 9 * 1024 + 16) * sizeof(uint32_t));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             attr_set = true;
@@ -315,7 +316,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+            hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), bin_lds + 6 * 1024 * sizeof(uint32_t), stream, P, geom.rank_rec,
                                img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
         }
         STAGE_CHECK("emit ranks");
@@ -329,20 +330,20 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             // some tile needs it.  The longest list was copied to the host right after the range scan, which
             // finished before the emit pass above even started: this wait does not stall the queue.
             hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                               bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
-                               img.blend_count, vp.grid_x);
+                               bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
+                               bin.blend_rec, img.blend_count);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
             if (g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
             if (max_tile_count > 2048)
                 hipLaunchKernelGGL((tile_sort_kernel<2048, 6144, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                                   bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
-                                   img.blend_count, vp.grid_x);
+                                   bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
+                                   bin.blend_rec, img.blend_count);
             if (max_tile_count > 6144)
                 hipLaunchKernelGGL((tile_sort_kernel<6144, 12288, true>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                                   bin.entries, bin.scratch, geom.rank_rec, bin.point_list, passes, bin.blend_rec,
-                                   img.blend_count, vp.grid_x);
+                                   bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
+                                   bin.blend_rec, img.blend_count);
         }
         STAGE_CHECK("tile sort");
     }
