@@ -151,16 +151,32 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
     M = sh.size(1) if sh.numel() != 0 else 0
     dev = means3D.device
     o = dict(device=dev, dtype=torch.float32)
-    dL_dmeans3D = torch.zeros((P, 3), **o)
-    dL_dmeans2D = torch.zeros((P, 3), **o)
-    dL_dcolors = torch.zeros((P, channels), **o)
-    dL_dconic = torch.zeros((P, 2, 2), **o)
-    dL_dopacity = torch.zeros((P, 1), **o)
-    dL_dcov3D = torch.zeros((P, 6), **o)
-    dL_dsh = torch.zeros((P, M, 3), **o)
-    dL_dscales = torch.zeros((P, 3), **o)
-    dL_drotations = torch.zeros((P, 4), **o)
-    dL_dmask = torch.zeros((P,), **o) if with_mask_depth else None
+    # The reference allocates ten zero tensors (rasterize_points.cu:151-159).  Same tensors here, carved from ONE
+    # zero-filled block: one fill launch instead of ten (each small fill costs a launch, ~5 us, on this part).
+    shapes = [("dL_dmeans3D", (P, 3)), ("dL_dmeans2D", (P, 3)), ("dL_dcolors", (P, channels)), ("dL_dconic", (P, 2, 2)),
+              ("dL_dopacity", (P, 1)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)),
+              ("dL_drotations", (P, 4))]
+    if with_mask_depth:
+        shapes.append(("dL_dmask", (P,)))
+    sizes = []
+    for _n, shp in shapes:
+        n = 1
+        for d in shp:
+            n *= d
+        sizes.append((n + 3) // 4 * 4)  # keep every tensor 16-byte aligned
+    flat = torch.zeros(sum(sizes), **o)
+    g = {}
+    off = 0
+    for (name, shp), n in zip(shapes, sizes):
+        cnt = 1
+        for d in shp:
+            cnt *= d
+        g[name] = flat[off:off + cnt].view(shp)
+        off += n
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic = g["dL_dmeans3D"], g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dconic"]
+    dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales = g["dL_dopacity"], g["dL_dcov3D"], g["dL_dsh"], g["dL_dscales"]
+    dL_drotations = g["dL_drotations"]
+    dL_dmask = g.get("dL_dmask")
     if P != 0:
         t = [_contig(x) for x in (background, means3D, sh, colors, scales, rotations, cov3D_precomp, viewmatrix,
                                    projmatrix, campos, dL_dout_color, dL_dout_mask, radii)]
