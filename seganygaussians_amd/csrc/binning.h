@@ -98,41 +98,53 @@ constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_TILES = 31 * 1024 - 64;  // LDS: one counter per tile + 37 KB of hand-off arrays must fit in 160 KB
 
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_total,
-                                                           uint2* __restrict__ ranges, int* __restrict__ num_rendered)
+                                                           uint2* __restrict__ ranges, int* __restrict__ num_rendered,
+                                                           uint32_t big_threshold, int big_limit,
+                                                           uint32_t* __restrict__ big_list)
 {
+    // thread t owns the contiguous items [t*per, (t+1)*per): local sums, one workgroup scan, local write-out.
+    // Items below big_limit with more than big_threshold entries are appended to big_list (count in big_list[0]).
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
     __shared__ uint32_t s_maxcount;
+    __shared__ uint32_t s_nbig;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         s_maxcount = 0;
-        s_carry = 0;
+        s_nbig = 0;
+    }
+    const int per = (ntiles + 1023) / 1024;
+    const int i0 = min(ntiles, tid * per), i1 = min(ntiles, i0 + per);
+    uint32_t sum = 0, mx = 0;
+    for (int i = i0; i < i1; i++) {
+        const uint32_t c = tile_total[i];
+        sum += c;
+        mx = max(mx, c);
+    }
+    const uint32_t incl = wave_inclusive_scan(sum, lane);
+    if (lane == 63) s_wave[wave] = incl;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    __syncthreads();
+    if (lane == 0 && mx) atomicMax(&s_maxcount, mx);
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t c = s_wave[w];
+        woff += w < wave ? c : 0u;
+        total += c;
+    }
+    uint32_t run = woff + incl - sum;
+    for (int i = i0; i < i1; i++) {
+        const uint32_t c = tile_total[i];
+        ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);
+        if (big_list != nullptr && i < big_limit && c > big_threshold) big_list[1 + atomicAdd(&s_nbig, 1u)] = (uint32_t)i;
+        run += c;
     }
     __syncthreads();
-    for (int base = 0; base < ntiles; base += 1024) {
-        const int t = base + tid;
-        const uint32_t c = t < ntiles ? tile_total[t] : 0u;
-        const uint32_t incl = wave_inclusive_scan(c, lane);
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += s_wave[w];
-        const uint32_t carry = s_carry;
-        const uint32_t excl = carry + woff + incl - c;
-        if (t < ntiles) ranges[t] = c ? make_uint2(excl, excl + c) : make_uint2(0u, 0u);
-        {
-            uint32_t m = c;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-            if (lane == 0 && m) atomicMax(&s_maxcount, m);
-        }
-        __syncthreads();
-        if (tid == 1023) s_carry = excl + c;
-        __syncthreads();
-    }
     if (tid == 0) {
-        num_rendered[0] = (int)s_carry;     // R (the host already has it from the preprocess pass; kept for checks)
-        num_rendered[1] = (int)s_maxcount;  // longest tile list
+        num_rendered[0] = (int)total;       // R (the host already has it from the preprocess pass; kept for checks)
+        num_rendered[1] = (int)s_maxcount;  // longest list
+        if (big_list != nullptr) big_list[0] = s_nbig;
     }
 }
 

@@ -1,0 +1,241 @@
+// depth_sort.h -- depth ranks of the Gaussians: sorted_idx[rank] and the per-rank geometry records.
+//
+// What the reference needs from its 64-bit (tile | depth) sort is, per tile, the order by (depth bits, Gaussian
+// index) (rasterizer_impl.cu:70-113, 296-308).  binning.h gets that from ONE ordering of the P Gaussians by
+// (depth bits, index): the dense rank.  A library radix sort of P key/value pairs is ~20 small launches (0.16 ms
+// at P = 1 M, launch-bound); here the ordering is produced by the same count / scan / scatter machinery as the tile
+// binning, with the float's own bit layout as the bucket function:
+//   1. bucket = (depth_bits - bits(0.2f)) >> 14 -- 16384 log-spaced buckets of 2^-9 relative width, monotonic in
+//      the key (every visible Gaussian has depth > 0.2, auxiliary.h:154); culled Gaussians go to one extra bucket;
+//   2. count per (workgroup slice, bucket) in LDS, scan over (bucket, slice), scan over buckets (binning.h);
+//   3. scatter (key - bits(0.2f), index) pairs to their bucket with LDS cursors (arrival order arbitrary);
+//   4. one workgroup per bucket sorts its pairs in LDS by (key, index) -- LSD radix over the index digits, then over
+//      the 14 key bits that differ inside a bucket -- and writes sorted_idx[rank] plus the 32-byte rank record
+//      (mean, conic, opacity, radius, id) that the binning passes read coalesced.  Buckets over 1024 pairs go to a
+//      second kernel (up to 8192 in LDS, beyond that ping-ponging in HBM): dense depth layers cost time, not
+//      correctness.
+#pragma once
+
+#include "binning.h"
+
+namespace mirast {
+
+constexpr int DS_NB = 16384;
+constexpr int DS_NBK = DS_NB + 1;  // + the bucket of culled Gaussians
+constexpr int DS_SHIFT = 14;
+constexpr uint32_t DS_K0 = 0x3E4CCCCDu;  // bits of 0.2f
+constexpr int DS_MAX_WG = 128;
+constexpr int DS_SMALL = 1024;   // pairs per bucket sorted by the one-workgroup-per-bucket kernel
+constexpr int DS_LARGE = 8192;   // pairs per bucket the second kernel holds in LDS
+
+__device__ __forceinline__ uint32_t depth_bucket(uint32_t key)
+{
+    if (key == 0xFFFFFFFFu) return (uint32_t)DS_NB;  // culled (geometry.h)
+    const uint32_t d = key > DS_K0 ? key - DS_K0 : 0u;
+    return min(d >> DS_SHIFT, (uint32_t)(DS_NB - 1));  // keys past the last bucket share it (sorted on all 32 bits)
+}
+
+inline int depth_workgroups(int P)
+{
+    const int blocks = (P + 1023) / 1024;
+    return blocks < 1 ? 1 : (blocks > DS_MAX_WG ? DS_MAX_WG : blocks);
+}
+
+// Count pass (EMIT = false) and scatter pass (EMIT = true); same structure as bin_ranks_kernel, one item per Gaussian.
+template <bool EMIT>
+__global__ void __launch_bounds__(1024) depth_bucket_kernel(int P, const uint32_t* __restrict__ depth_key,
+                                                            uint32_t* __restrict__ partial,
+                                                            const uint2* __restrict__ ranges, uint2* __restrict__ pairs,
+                                                            uint32_t* __restrict__ sorted_idx,
+                                                            BlendRec* __restrict__ rank_rec)
+{
+    extern __shared__ uint32_t s_dyn[];  // [DS_NBK] counters / cursors
+    const int tid = threadIdx.x;
+    uint32_t* my_partial = partial + (size_t)blockIdx.x * DS_NBK;
+    for (int b = tid; b < DS_NBK; b += 1024) s_dyn[b] = EMIT ? ranges[b].x + my_partial[b] : 0u;
+    __syncthreads();
+    for (int i = blockIdx.x * 1024 + tid; i < P; i += gridDim.x * 1024) {
+        const uint32_t key = depth_key[i];
+        const uint32_t b = depth_bucket(key);
+        if (EMIT) {
+            const uint32_t slot = atomicAdd(&s_dyn[b], 1u);
+            if (b < (uint32_t)DS_NB) {
+                // the pair carries key - K0 (same order as the key; the bucket is its high bits, so inside a bucket
+                // only its low 14 bits differ)
+                pairs[slot] = make_uint2(key > DS_K0 ? key - DS_K0 : 0u, (uint32_t)i);
+            } else {  // culled: ranks V..P-1 in arbitrary order, radius 0 (every later stage skips them)
+                BlendRec rec;
+                rec.xy = make_float2(0.f, 0.f);
+                rec.id = (uint32_t)i;
+                rec.pm = 0u;
+                rec.co = make_float4(0.f, 0.f, 0.f, 0.f);
+                rank_rec[slot] = rec;
+                sorted_idx[slot] = (uint32_t)i;
+            }
+        } else {
+            atomicAdd(&s_dyn[b], 1u);
+        }
+    }
+    if (!EMIT) {
+        __syncthreads();
+        for (int b = tid; b < DS_NBK; b += 1024) my_partial[b] = s_dyn[b];
+    }
+}
+
+// ---- (key, value) pair storage for the bucket sort: LDS arrays or one uint2 array in HBM ----------------
+struct LdsPairs {
+    uint32_t* k;
+    uint32_t* v;
+    __device__ __forceinline__ uint32_t key(int i) const { return k[i]; }
+    __device__ __forceinline__ uint32_t val(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, uint32_t kk, uint32_t vv) const
+    {
+        k[i] = kk;
+        v[i] = vv;
+    }
+};
+struct GlobalPairs {
+    uint2* p;
+    __device__ __forceinline__ uint32_t key(int i) const { return p[i].x; }
+    __device__ __forceinline__ uint32_t val(int i) const { return p[i].y; }
+    __device__ __forceinline__ void set(int i, uint32_t kk, uint32_t vv) const { p[i] = make_uint2(kk, vv); }
+};
+
+// One stable 8-bit LSD pass over pairs (digit taken from the value when BY_VAL, else from the key); same scheme as
+// radix_pass in binning.h: each wave owns a contiguous quarter, ballot-match ranking inside a wave.
+template <bool BY_VAL, typename Src, typename Dst>
+__device__ __forceinline__ void radix_pass_pairs(Src src, Dst dst, int n, int shift, uint32_t (*s_hist)[256],
+                                                 uint32_t* s_wsum, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int chunks = (n + 63) >> 6;
+    const int cpw = (chunks + 3) >> 2;
+    const int begin = min(n, wave * cpw * 64), end = min(n, (wave + 1) * cpw * 64);
+    for (int d = tid; d < 4 * 256; d += 256) (&s_hist[0][0])[d] = 0;
+    __syncthreads();
+
+    auto match = [&](uint32_t digit, bool active, uint32_t& rank_in_wave, uint32_t& cnt) {
+        uint64_t m = ballot64(active);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t bal = ballot64(active && ((digit >> b) & 1u));
+            m &= ((digit >> b) & 1u) ? bal : ~bal;
+        }
+        rank_in_wave = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        cnt = (uint32_t)__builtin_popcountll(m);
+    };
+
+    for (int i0 = begin; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const bool active = i < end;
+        const uint32_t word = active ? (BY_VAL ? src.val(i) : src.key(i)) : 0u;
+        const uint32_t digit = (word >> shift) & 0xFFu;
+        uint32_t rk, cnt;
+        match(digit, active, rk, cnt);
+        if (active && rk == 0) s_hist[wave][digit] += cnt;
+    }
+    __syncthreads();
+    {
+        const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid], c3 = s_hist[3][tid];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        const uint32_t incl = wave_inclusive_scan(tot, lane);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += s_wsum[w];
+        const uint32_t excl = woff + incl - tot;
+        s_hist[0][tid] = excl;
+        s_hist[1][tid] = excl + c0;
+        s_hist[2][tid] = excl + c0 + c1;
+        s_hist[3][tid] = excl + c0 + c1 + c2;
+    }
+    __syncthreads();
+    for (int i0 = begin; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const bool active = i < end;
+        const uint32_t kk = active ? src.key(i) : 0u, vv = active ? src.val(i) : 0u;
+        const uint32_t digit = ((BY_VAL ? vv : kk) >> shift) & 0xFFu;
+        uint32_t rk, cnt;
+        match(digit, active, rk, cnt);
+        uint32_t off = 0;
+        if (active) off = s_hist[wave][digit] + rk;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (active && rk == cnt - 1) s_hist[wave][digit] = off + 1;
+        if (active) dst.set((int)off, kk, vv);
+    }
+    __syncthreads();
+}
+
+// Sorts the pairs of one bucket by (key, index) and writes sorted_idx / rank_rec for its ranks.
+// BIG = false: one workgroup per bucket, buckets of 1..CAP pairs.  BIG = true: workgroups walk the list of buckets
+// with more than LO pairs (built by tile_ranges_kernel); up to CAP pairs in LDS, more than that in HBM.
+template <int LO, int CAP, bool BIG>
+__global__ void __launch_bounds__(256) depth_bucket_sort_kernel(const uint2* __restrict__ ranges,
+                                                                const uint32_t* __restrict__ big_list,
+                                                                uint2* __restrict__ pairs, uint2* __restrict__ pairs_tmp,
+                                                                int idx_passes, const float2* __restrict__ points_xy,
+                                                                const float4* __restrict__ conic_opacity,
+                                                                const int* __restrict__ radii,
+                                                                uint32_t* __restrict__ sorted_idx,
+                                                                BlendRec* __restrict__ rank_rec)
+{
+    __shared__ uint32_t s_k[2][CAP];
+    __shared__ uint32_t s_v[2][CAP];
+    __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_wsum[4];
+    const int tid = threadIdx.x;
+    const int nwork = BIG ? (int)big_list[0] : 1;
+    for (int j = BIG ? (int)blockIdx.x : 0; j < nwork; j += BIG ? (int)gridDim.x : 1) {
+        const int b = BIG ? (int)big_list[1 + j] : (int)blockIdx.x;
+        const uint2 range = ranges[b];
+        const int n = (int)(range.y - range.x);
+        if (!BIG && (n == 0 || n > CAP)) return;
+        const int key_passes = b == DS_NB - 1 ? 4 : 2;  // inside a bucket only the low 14 key bits differ
+        auto finalize = [&](auto src) {
+            for (int i = tid; i < n; i += 256) {
+                const uint32_t g = src.val(i);
+                const int rad = radii[g];
+                BlendRec rec;
+                rec.xy = points_xy[g];
+                rec.id = g;
+                rec.pm = (uint32_t)(rad > 0 ? rad : 0);
+                rec.co = conic_opacity[g];
+                rank_rec[range.x + i] = rec;
+                sorted_idx[range.x + i] = g;
+            }
+        };
+        if (n <= CAP) {
+            for (int i = tid; i < n; i += 256) {
+                const uint2 p = pairs[range.x + i];
+                s_k[0][i] = p.x;
+                s_v[0][i] = p.y;
+            }
+            __syncthreads();
+            int cur = 0;
+            for (int p = 0; p < idx_passes; p++, cur ^= 1)
+                radix_pass_pairs<true>(LdsPairs{s_k[cur], s_v[cur]}, LdsPairs{s_k[cur ^ 1], s_v[cur ^ 1]}, n, 8 * p, s_hist, s_wsum, tid);
+            for (int p = 0; p < key_passes; p++, cur ^= 1)
+                radix_pass_pairs<false>(LdsPairs{s_k[cur], s_v[cur]}, LdsPairs{s_k[cur ^ 1], s_v[cur ^ 1]}, n, 8 * p, s_hist, s_wsum, tid);
+            finalize(LdsPairs{s_k[cur], s_v[cur]});
+        } else {
+            uint2* a = pairs + range.x;
+            uint2* t = pairs_tmp + range.x;
+            for (int p = 0; p < idx_passes; p++) {
+                radix_pass_pairs<true>(GlobalPairs{a}, GlobalPairs{t}, n, 8 * p, s_hist, s_wsum, tid);
+                uint2* x = a;
+                a = t;
+                t = x;
+            }
+            for (int p = 0; p < key_passes; p++) {
+                radix_pass_pairs<false>(GlobalPairs{a}, GlobalPairs{t}, n, 8 * p, s_hist, s_wsum, tid);
+                uint2* x = a;
+                a = t;
+                t = x;
+            }
+            finalize(GlobalPairs{a});
+        }
+        __syncthreads();  // LDS reuse by the next bucket
+    }
+}
+
+}  // namespace mirast

@@ -113,15 +113,14 @@ __device__ __forceinline__ float3 computeColorFromSH(int idx, int deg, int max_c
 // Forward preprocess: CF/cuda_rasterizer/forward.cu:159-259 (+ in_frustum, auxiliary.h:139-164).
 // `culled_prefiltered` is incremented when prefiltered is set and a point is culled (the reference
 // printf+__trap()s the whole context there; we report an error instead).
-// gfx950 additions (binning.h): writes the 32-bit depth sort key (0xFFFFFFFF for culled Gaussians) and the
-// identity index array for the depth sort, and accumulates R = sum of tiles_touched of the visible Gaussians.
+// gfx950 additions (binning.h): writes the 32-bit depth sort key (0xFFFFFFFF for culled Gaussians) and accumulates R = sum of tiles_touched of the visible Gaussians.
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     uint8_t* __restrict__ clamped, const float* __restrict__ cov3D_precomp, int colors_given, ViewParams vp,
     int* __restrict__ radii, float2* __restrict__ points_xy_image, float* __restrict__ depths,
     float* __restrict__ cov3Ds, float* __restrict__ rgb, float4* __restrict__ conic_opacity,
-    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ idx_iota,
+    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key,
     int* __restrict__ r_slots, int prefiltered, int* __restrict__ culled_prefiltered)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,7 +189,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         radii[idx] = my_radii;
         tiles_touched[idx] = my_tiles;
         depth_key[idx] = my_key;
-        idx_iota[idx] = (uint32_t)idx;
     }
     // R = sum of tiles_touched over the Gaussians that later stages treat as visible (what InclusiveSum's last
     // element is in the reference, rasterizer_impl.cu:277-281).  One atomic per wave, spread over R_SLOTS lines:

@@ -4,7 +4,6 @@
 #include "../../include/mi_rast.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +11,7 @@
 #include <string>
 
 #include "binning.h"
+#include "depth_sort.h"
 #include "blend_bwd.h"
 #include "blend_bwd_mfma.h"
 #include "blend_fwd.h"
@@ -60,12 +60,53 @@ struct Carver {
     }
 };
 
-size_t depth_sort_temp_bytes(int P)
+// Scratch of the depth ordering (depth_sort.h), carved from the geometry buffer's sort_temp field.
+struct DepthScratch {
+    int* cull_counter;    // first word: prefiltered-cull counter (live before the ordering starts)
+    uint2* pairs;         // [P] (depth bits, index), bucketed
+    uint2* pairs_tmp;     // [P] ping-pong for buckets too long for LDS
+    uint32_t* partial;    // [DS_MAX_WG][DS_NBK]
+    uint32_t* total;      // [DS_NBK]
+    uint2* ranges;        // [DS_NBK]
+    uint32_t* big_list;   // [1 + DS_NB]
+    int* out2;            // {V + culled == P, longest bucket}
+};
+size_t depth_sort_temp_bytes(int P, size_t* offs = nullptr)
 {
-    size_t n = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, n, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                             (uint32_t*)nullptr, P > 0 ? P : 1);
-    return n;
+    const size_t p = P > 0 ? (size_t)P : 1;
+    size_t o[8];
+    size_t at = 256;
+    auto take = [&](size_t n) {
+        const size_t r = at;
+        at = (at + n + 255) & ~(size_t)255;
+        return r;
+    };
+    o[0] = 0;
+    o[1] = take(p * sizeof(uint2));
+    o[2] = take(p * sizeof(uint2));
+    o[3] = take((size_t)DS_MAX_WG * DS_NBK * sizeof(uint32_t));
+    o[4] = take((size_t)DS_NBK * sizeof(uint32_t));
+    o[5] = take((size_t)DS_NBK * sizeof(uint2));
+    o[6] = take((size_t)(DS_NB + 2) * sizeof(uint32_t));
+    o[7] = take(16);
+    if (offs)
+        for (int i = 0; i < 8; i++) offs[i] = o[i];
+    return at;
+}
+DepthScratch depth_scratch(char* base, int P)
+{
+    size_t o[8];
+    depth_sort_temp_bytes(P, o);
+    DepthScratch d;
+    d.cull_counter = (int*)(base + o[0]);
+    d.pairs = (uint2*)(base + o[1]);
+    d.pairs_tmp = (uint2*)(base + o[2]);
+    d.partial = (uint32_t*)(base + o[3]);
+    d.total = (uint32_t*)(base + o[4]);
+    d.ranges = (uint2*)(base + o[5]);
+    d.big_list = (uint32_t*)(base + o[6]);
+    d.out2 = (int*)(base + o[7]);
+    return d;
 }
 
 // ---- host-side scratch for the num_rendered read-back: pinned word + event, one per host thread -------
@@ -141,7 +182,6 @@ struct GeomPtrs {
     uint32_t* sorted_key;
     uint32_t* sorted_idx;
     char* sort_temp;
-    size_t sort_temp_size;
     float* bwd_pack;  // [P,8] packed per-Gaussian field gradients (backward scratch)
     BlendRec* rank_rec;  // [P] geometry records in depth-rank order (binning.h)
 };
@@ -180,8 +220,7 @@ GeomPtrs geom_from(char* base, int P)
     g.sorted_key = (uint32_t*)(base + off[MI_GEOM_SORTED_KEY]);
     g.sorted_idx = (uint32_t*)(base + off[MI_GEOM_SORTED_IDX]);
     g.sort_temp = base + off[MI_GEOM_SORT_TEMP];
-    g.sort_temp_size = depth_sort_temp_bytes(P);
-    g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
+        g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
     g.rank_rec = (BlendRec*)(base + off[MI_GEOM_RANK_REC]);
     return g;
 }
@@ -251,7 +290,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
-                           geom.depth_key, geom.idx_iota, img.num_rendered, prefiltered, cull_counter);
+                           geom.depth_key, img.num_rendered, prefiltered, cull_counter);
     }
     STAGE_CHECK("preprocess");
     if (prefiltered) {
@@ -268,10 +307,31 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
     {
         StageTimer t(stream, MI_STAGE_DEPTH_SORT);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(geom.sort_temp, geom.sort_temp_size, geom.depth_key, geom.sorted_key,
-                                                   geom.idx_iota, geom.sorted_idx, P, 0, 32, stream));
-        hipLaunchKernelGGL(build_rank_records_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.sorted_idx,
-                           geom.means2D, geom.conic_opacity, radii, geom.rank_rec);
+        // depth ordering -> sorted_idx[rank] and the per-rank geometry records (depth_sort.h): 6 launches
+        static bool ds_attr = false;
+        if (!ds_attr) {
+            HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DS_NBK * (int)sizeof(uint32_t)));
+            HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DS_NBK * (int)sizeof(uint32_t)));
+            ds_attr = true;
+        }
+        const DepthScratch ds = depth_scratch(geom.sort_temp, P);
+        const int nwg_d = depth_workgroups(P);
+        int idx_bits = 1;
+        while ((1ll << idx_bits) < (long long)P) idx_bits++;
+        const int idx_passes = (idx_bits + 7) / 8;
+        hipLaunchKernelGGL(depth_bucket_kernel<false>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
+                           geom.depth_key, ds.partial, (const uint2*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (BlendRec*)nullptr);
+        hipLaunchKernelGGL(scan_partials_kernel, dim3((DS_NBK + 63) / 64), dim3(1024), 0, stream, DS_NBK, nwg_d, ds.partial, ds.total);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, stream, DS_NBK, ds.total, ds.ranges, ds.out2,
+                           (uint32_t)DS_SMALL, DS_NB, ds.big_list);
+        hipLaunchKernelGGL(depth_bucket_kernel<true>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
+                           geom.depth_key, ds.partial, ds.ranges, ds.pairs, geom.sorted_idx, geom.rank_rec);
+        hipLaunchKernelGGL((depth_bucket_sort_kernel<0, DS_SMALL, false>), dim3(DS_NB), dim3(256), 0, stream, ds.ranges,
+                           (const uint32_t*)nullptr, ds.pairs, ds.pairs_tmp, idx_passes, geom.means2D, geom.conic_opacity,
+                           radii, geom.sorted_idx, geom.rank_rec);
+        hipLaunchKernelGGL((depth_bucket_sort_kernel<DS_SMALL, DS_LARGE, true>), dim3(256), dim3(256), 0, stream, ds.ranges,
+                           ds.big_list, ds.pairs, ds.pairs_tmp, idx_passes, geom.means2D, geom.conic_opacity, radii,
+                           geom.sorted_idx, geom.rank_rec);
     }
     STAGE_CHECK("depth sort");
     const int nwg = bin_workgroups(P);
@@ -293,7 +353,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, stream, ntiles, img.tile_cursor, img.ranges,
-                           img.num_rendered + R_SLOTS * R_SLOT_STRIDE);
+                           img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr);
     }
     STAGE_CHECK("tile scan");
     HIP_TRY(hipMemcpyAsync(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE, img.num_rendered + R_SLOTS * R_SLOT_STRIDE,

@@ -1,3 +1,3 @@
-REPO=$(pwd); OUT=$REPO/gpurun_out/tl; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o tl -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/log.txt 2>&1
-cd $REPO; f=$(find $OUT -name "*kernel_trace.csv" | head -1); python tools/timeline.py $f
+timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 120 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['stages_ms'])"
+timeout 200 python bench.py --config cfg5 --steps 8 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['stages_ms'])"
