@@ -10,7 +10,7 @@ from .build import LIB_PATH
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 MI_GEOM_FIELDS = ["depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped", "tiles_touched",
-                  "depth_key", "idx_iota", "sorted_key", "sorted_idx", "sort_temp", "bwd_pack", "rank_rec"]
+                  "depth_key", "index_rec", "sorted_idx", "sort_temp", "bwd_pack", "rank_rec"]
 MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed", "tile_count", "tile_cursor", "num_rendered", "blend_count", "tile_nsurv"]
 MI_BIN_FIELDS = ["entries", "scratch", "point_list", "blend_rec"]
 MI_STAGES = ["preprocess", "depth_sort", "tile_scan", "emit", "tile_sort", "blend_fwd", "blend_bwd", "geom_bwd"]

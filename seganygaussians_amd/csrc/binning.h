@@ -102,8 +102,10 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uin
                                                            uint32_t big_threshold, int big_limit,
                                                            uint32_t* __restrict__ big_list)
 {
-    // thread t owns the contiguous items [t*per, (t+1)*per): local sums, one workgroup scan, local write-out.
-    // Items below big_limit with more than big_threshold entries are appended to big_list (count in big_list[0]).
+    // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
+    // one workgroup scan joins the pieces, and the ranges leave coalesced again.  Items below big_limit with more
+    // than big_threshold entries are appended to big_list (count in big_list[0], order arbitrary).
+    extern __shared__ uint32_t s_val[];  // [ntiles + 1]
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_maxcount;
     __shared__ uint32_t s_nbig;
@@ -112,11 +114,14 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uin
         s_maxcount = 0;
         s_nbig = 0;
     }
+    for (int i = tid; i < ntiles; i += 1024) s_val[i] = tile_total[i];
+    __syncthreads();
     const int per = (ntiles + 1023) / 1024;
     const int i0 = min(ntiles, tid * per), i1 = min(ntiles, i0 + per);
     uint32_t sum = 0, mx = 0;
     for (int i = i0; i < i1; i++) {
-        const uint32_t c = tile_total[i];
+        const uint32_t c = s_val[i];
+        s_val[i] = sum;  // exclusive prefix inside the piece
         sum += c;
         mx = max(mx, c);
     }
@@ -133,12 +138,14 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uin
         woff += w < wave ? c : 0u;
         total += c;
     }
-    uint32_t run = woff + incl - sum;
-    for (int i = i0; i < i1; i++) {
-        const uint32_t c = tile_total[i];
-        ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);
-        if (big_list != nullptr && i < big_limit && c > big_threshold) big_list[1 + atomicAdd(&s_nbig, 1u)] = (uint32_t)i;
-        run += c;
+    const uint32_t piece_base = woff + incl - sum;
+    for (int i = i0; i < i1; i++) s_val[i] += piece_base;
+    if (tid == 0) s_val[ntiles] = total;
+    __syncthreads();
+    for (int i = tid; i < ntiles; i += 1024) {
+        const uint32_t lo = s_val[i], hi = s_val[i + 1];
+        ranges[i] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+        if (big_list != nullptr && i < big_limit && hi - lo > big_threshold) big_list[1 + atomicAdd(&s_nbig, 1u)] = (uint32_t)i;
     }
     __syncthreads();
     if (tid == 0) {

@@ -5,12 +5,13 @@
 // (depth bits, index): the dense rank.  A library radix sort of P key/value pairs is ~20 small launches (0.16 ms
 // at P = 1 M, launch-bound); here the ordering is produced by the same count / scan / scatter machinery as the tile
 // binning, with the float's own bit layout as the bucket function:
-//   1. bucket = (depth_bits - bits(0.2f)) >> 14 -- 16384 log-spaced buckets of 2^-9 relative width, monotonic in
-//      the key (every visible Gaussian has depth > 0.2, auxiliary.h:154); culled Gaussians go to one extra bucket;
+//   1. bucket = (depth_bits - min_bits) >> s, with s the smallest shift that maps the view's key range (min / max
+//      from the preprocess pass) onto <= 16384 buckets: log-spaced in depth, monotonic in the key, between 8192 and
+//      16384 of them in use; culled Gaussians go to one extra bucket;
 //   2. count per (workgroup slice, bucket) in LDS, scan over (bucket, slice), scan over buckets (binning.h);
-//   3. scatter (key - bits(0.2f), index) pairs to their bucket with LDS cursors (arrival order arbitrary);
-//   4. one workgroup per bucket sorts its pairs in LDS by (key, index) -- LSD radix over the index digits, then over
-//      the 14 key bits that differ inside a bucket -- and writes sorted_idx[rank] plus the 32-byte rank record
+//   3. scatter (key - min_bits, index) pairs to their bucket with LDS cursors (arrival order arbitrary);
+//   4. one workgroup per bucket sorts its pairs in LDS by (key, index) -- by counting for buckets up to 512 pairs,
+//      else LSD radix over the index digits, then over the s key bits that differ inside a bucket -- and writes sorted_idx[rank] plus the 32-byte rank record
 //      (mean, conic, opacity, radius, id) that the binning passes read coalesced.  Buckets over 1024 pairs go to a
 //      second kernel (up to 8192 in LDS, beyond that ping-ponging in HBM): dense depth layers cost time, not
 //      correctness.
@@ -22,17 +23,38 @@ namespace mirast {
 
 constexpr int DS_NB = 16384;
 constexpr int DS_NBK = DS_NB + 1;  // + the bucket of culled Gaussians
-constexpr int DS_SHIFT = 14;
-constexpr uint32_t DS_K0 = 0x3E4CCCCDu;  // bits of 0.2f
 constexpr int DS_MAX_WG = 128;
 constexpr int DS_SMALL = 1024;   // pairs per bucket sorted by the one-workgroup-per-bucket kernel
+constexpr int DS_COUNTING = 512;  // buckets up to this size are ranked by counting instead of radix passes
 constexpr int DS_LARGE = 8192;   // pairs per bucket the second kernel holds in LDS
 
-__device__ __forceinline__ uint32_t depth_bucket(uint32_t key)
+// Key range of the view -> {min key, bucket shift}.  Call from every thread (reads 2 x R_SLOTS words, L2-resident).
+struct DepthMap {
+    uint32_t kmin;
+    int shift;
+};
+__device__ __forceinline__ DepthMap depth_map(const int* __restrict__ r_slots)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t inv_min = (uint32_t)r_slots[(lane % R_SLOTS) * R_SLOT_STRIDE + 1];
+    uint32_t mx = (uint32_t)r_slots[(lane % R_SLOTS) * R_SLOT_STRIDE + 2];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        inv_min = max(inv_min, (uint32_t)__shfl_xor((int)inv_min, o, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    }
+    DepthMap m;
+    m.kmin = ~inv_min;
+    const uint32_t span = mx >= m.kmin ? mx - m.kmin : 0u;  // no visible Gaussian: kmin = 0xFFFFFFFF, span 0
+    int s = 0;
+    while (s < 32 && (span >> s) >= (uint32_t)DS_NB) s++;
+    m.shift = s;
+    return m;
+}
+__device__ __forceinline__ uint32_t depth_bucket(uint32_t key, const DepthMap& m)
 {
     if (key == 0xFFFFFFFFu) return (uint32_t)DS_NB;  // culled (geometry.h)
-    const uint32_t d = key > DS_K0 ? key - DS_K0 : 0u;
-    return min(d >> DS_SHIFT, (uint32_t)(DS_NB - 1));  // keys past the last bucket share it (sorted on all 32 bits)
+    return (key - m.kmin) >> m.shift;
 }
 
 inline int depth_workgroups(int P)
@@ -47,22 +69,24 @@ __global__ void __launch_bounds__(1024) depth_bucket_kernel(int P, const uint32_
                                                             uint32_t* __restrict__ partial,
                                                             const uint2* __restrict__ ranges, uint2* __restrict__ pairs,
                                                             uint32_t* __restrict__ sorted_idx,
-                                                            BlendRec* __restrict__ rank_rec)
+                                                            BlendRec* __restrict__ rank_rec,
+                                                            const int* __restrict__ r_slots)
 {
     extern __shared__ uint32_t s_dyn[];  // [DS_NBK] counters / cursors
     const int tid = threadIdx.x;
+    const DepthMap dm = depth_map(r_slots);
     uint32_t* my_partial = partial + (size_t)blockIdx.x * DS_NBK;
     for (int b = tid; b < DS_NBK; b += 1024) s_dyn[b] = EMIT ? ranges[b].x + my_partial[b] : 0u;
     __syncthreads();
     for (int i = blockIdx.x * 1024 + tid; i < P; i += gridDim.x * 1024) {
         const uint32_t key = depth_key[i];
-        const uint32_t b = depth_bucket(key);
+        const uint32_t b = depth_bucket(key, dm);
         if (EMIT) {
             const uint32_t slot = atomicAdd(&s_dyn[b], 1u);
             if (b < (uint32_t)DS_NB) {
-                // the pair carries key - K0 (same order as the key; the bucket is its high bits, so inside a bucket
-                // only its low 14 bits differ)
-                pairs[slot] = make_uint2(key > DS_K0 ? key - DS_K0 : 0u, (uint32_t)i);
+                // the pair carries key - min key (same order as the key; the bucket is its high bits, so inside a
+                // bucket only its low `shift` bits differ)
+                pairs[slot] = make_uint2(key - dm.kmin, (uint32_t)i);
             } else {  // culled: ranks V..P-1 in arbitrary order, radius 0 (every later stage skips them)
                 BlendRec rec;
                 rec.xy = make_float2(0.f, 0.f);
@@ -173,34 +197,27 @@ template <int LO, int CAP, bool BIG>
 __global__ void __launch_bounds__(256) depth_bucket_sort_kernel(const uint2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ big_list,
                                                                 uint2* __restrict__ pairs, uint2* __restrict__ pairs_tmp,
-                                                                int idx_passes, const float2* __restrict__ points_xy,
-                                                                const float4* __restrict__ conic_opacity,
-                                                                const int* __restrict__ radii,
+                                                                int idx_passes, const BlendRec* __restrict__ index_rec,
                                                                 uint32_t* __restrict__ sorted_idx,
-                                                                BlendRec* __restrict__ rank_rec)
+                                                                BlendRec* __restrict__ rank_rec,
+                                                                const int* __restrict__ r_slots)
 {
     __shared__ uint32_t s_k[2][CAP];
     __shared__ uint32_t s_v[2][CAP];
     __shared__ uint32_t s_hist[4][256];
     __shared__ uint32_t s_wsum[4];
     const int tid = threadIdx.x;
+    const int key_passes = (depth_map(r_slots).shift + 7) / 8;  // inside a bucket only the low `shift` key bits differ
     const int nwork = BIG ? (int)big_list[0] : 1;
     for (int j = BIG ? (int)blockIdx.x : 0; j < nwork; j += BIG ? (int)gridDim.x : 1) {
         const int b = BIG ? (int)big_list[1 + j] : (int)blockIdx.x;
         const uint2 range = ranges[b];
         const int n = (int)(range.y - range.x);
         if (!BIG && (n == 0 || n > CAP)) return;
-        const int key_passes = b == DS_NB - 1 ? 4 : 2;  // inside a bucket only the low 14 key bits differ
         auto finalize = [&](auto src) {
             for (int i = tid; i < n; i += 256) {
                 const uint32_t g = src.val(i);
-                const int rad = radii[g];
-                BlendRec rec;
-                rec.xy = points_xy[g];
-                rec.id = g;
-                rec.pm = (uint32_t)(rad > 0 ? rad : 0);
-                rec.co = conic_opacity[g];
-                rank_rec[range.x + i] = rec;
+                rank_rec[range.x + i] = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
                 sorted_idx[range.x + i] = g;
             }
         };
@@ -212,6 +229,23 @@ __global__ void __launch_bounds__(256) depth_bucket_sort_kernel(const uint2* __r
             }
             __syncthreads();
             int cur = 0;
+            if (n <= DS_COUNTING) {
+                // short bucket (the common case): rank by counting -- every pair is compared with every other one
+                // through LDS broadcast reads; (key, index) pairs are distinct, so the ranks are a permutation
+                for (int e = tid; e < n; e += 256) {
+                    const uint32_t mk = s_k[0][e], mv = s_v[0][e];
+                    const uint64_t mine = ((uint64_t)mk << 32) | mv;
+                    int rank = 0;
+#pragma unroll 4
+                    for (int q = 0; q < n; q++) rank += ((((uint64_t)s_k[0][q]) << 32) | s_v[0][q]) < mine ? 1 : 0;
+                    s_k[1][rank] = mk;
+                    s_v[1][rank] = mv;
+                }
+                __syncthreads();
+                finalize(LdsPairs{s_k[1], s_v[1]});
+                __syncthreads();
+                continue;
+            }
             for (int p = 0; p < idx_passes; p++, cur ^= 1)
                 radix_pass_pairs<true>(LdsPairs{s_k[cur], s_v[cur]}, LdsPairs{s_k[cur ^ 1], s_v[cur ^ 1]}, n, 8 * p, s_hist, s_wsum, tid);
             for (int p = 0; p < key_passes; p++, cur ^= 1)

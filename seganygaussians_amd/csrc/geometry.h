@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     uint8_t* __restrict__ clamped, const float* __restrict__ cov3D_precomp, int colors_given, ViewParams vp,
     int* __restrict__ radii, float2* __restrict__ points_xy_image, float* __restrict__ depths,
     float* __restrict__ cov3Ds, float* __restrict__ rgb, float4* __restrict__ conic_opacity,
-    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key,
+    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, BlendRec* __restrict__ index_rec,
     int* __restrict__ r_slots, int prefiltered, int* __restrict__ culled_prefiltered)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,6 +183,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             // duplicateWithKeys recomputes the rect from the stored int radius (rasterizer_impl.cu:91)
             getRect(point_image.x, point_image.y, my_radii, rect_min, rect_max, vp.grid_x, vp.grid_y);
             my_key = __float_as_uint(p_view.z);
+            // everything the binning stages need of this Gaussian in one 32-byte record (depth_sort.h gathers it once)
+            BlendRec rec;
+            rec.xy = point_image;
+            rec.id = (uint32_t)idx;
+            rec.pm = (uint32_t)my_radii;
+            rec.co = make_float4(conic.x, conic.y, conic.z, opacities[idx]);
+            index_rec[idx] = rec;
         }
     } while (0);
     if (idx < P) {
@@ -191,13 +198,24 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         depth_key[idx] = my_key;
     }
     // R = sum of tiles_touched over the Gaussians that later stages treat as visible (what InclusiveSum's last
-    // element is in the reference, rasterizer_impl.cu:277-281).  One atomic per wave, spread over R_SLOTS lines:
-    // same-line L2 atomics serialise at ~22 ns each.
+    // element is in the reference, rasterizer_impl.cu:277-281), and the range of their depth keys (depth_sort.h).
+    // Three atomics per wave, spread over R_SLOTS lines: same-line L2 atomics serialise at ~22 ns each.
+    // Line layout: [0] R partial sum, [1] max of ~key (= ~min key), [2] max key; all start at 0.
     {
         uint32_t sum = (rect_max.x - rect_min.x) * (rect_max.y - rect_min.y);
+        uint32_t inv_min = my_key == 0xFFFFFFFFu ? 0u : ~my_key, mx = my_key == 0xFFFFFFFFu ? 0u : my_key;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
-        if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&r_slots[(blockIdx.x % R_SLOTS) * R_SLOT_STRIDE], (int)sum);
+        for (int o = 32; o >= 1; o >>= 1) {
+            sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+            inv_min = max(inv_min, (uint32_t)__shfl_xor((int)inv_min, o, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0 && sum) {
+            int* line = &r_slots[(blockIdx.x % R_SLOTS) * R_SLOT_STRIDE];
+            atomicAdd(&line[0], (int)sum);
+            atomicMax(reinterpret_cast<uint32_t*>(&line[1]), inv_min);
+            atomicMax(reinterpret_cast<uint32_t*>(&line[2]), mx);
+        }
     }
 }
 

@@ -178,8 +178,7 @@ struct GeomPtrs {
     uint8_t* clamped;
     uint32_t* tiles_touched;
     uint32_t* depth_key;
-    uint32_t* idx_iota;
-    uint32_t* sorted_key;
+    BlendRec* index_rec;  // [P] {mean, id, radius, conic + opacity} in index order (written by the preprocess pass)
     uint32_t* sorted_idx;
     char* sort_temp;
     float* bwd_pack;  // [P,8] packed per-Gaussian field gradients (backward scratch)
@@ -216,8 +215,7 @@ GeomPtrs geom_from(char* base, int P)
     g.clamped = (uint8_t*)(base + off[MI_GEOM_CLAMPED]);
     g.tiles_touched = (uint32_t*)(base + off[MI_GEOM_TILES_TOUCHED]);
     g.depth_key = (uint32_t*)(base + off[MI_GEOM_DEPTH_KEY]);
-    g.idx_iota = (uint32_t*)(base + off[MI_GEOM_IDX_IOTA]);
-    g.sorted_key = (uint32_t*)(base + off[MI_GEOM_SORTED_KEY]);
+    g.index_rec = (BlendRec*)(base + off[MI_GEOM_INDEX_REC]);
     g.sorted_idx = (uint32_t*)(base + off[MI_GEOM_SORTED_IDX]);
     g.sort_temp = base + off[MI_GEOM_SORT_TEMP];
         g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
@@ -290,7 +288,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
-                           geom.depth_key, img.num_rendered, prefiltered, cull_counter);
+                           geom.depth_key, geom.index_rec, img.num_rendered, prefiltered, cull_counter);
     }
     STAGE_CHECK("preprocess");
     if (prefiltered) {
@@ -300,6 +298,21 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         if (culled)
             return fail(MI_RAST_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");
     }
+    {
+        static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
+        if (!attr_set) {
+            const int max_lds = (int)((BIN_MAX_TILES + 9 * 1024 + 16) * sizeof(uint32_t));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (BIN_MAX_TILES + 1) * (int)sizeof(uint32_t)));
+            HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        DS_NBK * (int)sizeof(uint32_t)));
+            HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        DS_NBK * (int)sizeof(uint32_t)));
+            attr_set = true;
+        }
+    }
     // R is known after the preprocess pass; its copy to the host overlaps the depth sort and the counting passes.
     if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host buffer / event");
     HIP_TRY(hipMemcpyAsync(g_host_sync.pinned, img.num_rendered, R_SLOTS * R_SLOT_STRIDE * sizeof(int),
@@ -308,43 +321,29 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     {
         StageTimer t(stream, MI_STAGE_DEPTH_SORT);
         // depth ordering -> sorted_idx[rank] and the per-rank geometry records (depth_sort.h): 6 launches
-        static bool ds_attr = false;
-        if (!ds_attr) {
-            HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DS_NBK * (int)sizeof(uint32_t)));
-            HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DS_NBK * (int)sizeof(uint32_t)));
-            ds_attr = true;
-        }
         const DepthScratch ds = depth_scratch(geom.sort_temp, P);
         const int nwg_d = depth_workgroups(P);
         int idx_bits = 1;
         while ((1ll << idx_bits) < (long long)P) idx_bits++;
         const int idx_passes = (idx_bits + 7) / 8;
         hipLaunchKernelGGL(depth_bucket_kernel<false>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
-                           geom.depth_key, ds.partial, (const uint2*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (BlendRec*)nullptr);
+                           geom.depth_key, ds.partial, (const uint2*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (BlendRec*)nullptr,
+                           (const int*)img.num_rendered);
         hipLaunchKernelGGL(scan_partials_kernel, dim3((DS_NBK + 63) / 64), dim3(1024), 0, stream, DS_NBK, nwg_d, ds.partial, ds.total);
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, stream, DS_NBK, ds.total, ds.ranges, ds.out2,
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), (DS_NBK + 1) * sizeof(uint32_t), stream, DS_NBK, ds.total, ds.ranges, ds.out2,
                            (uint32_t)DS_SMALL, DS_NB, ds.big_list);
         hipLaunchKernelGGL(depth_bucket_kernel<true>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
-                           geom.depth_key, ds.partial, ds.ranges, ds.pairs, geom.sorted_idx, geom.rank_rec);
+                           geom.depth_key, ds.partial, ds.ranges, ds.pairs, geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
         hipLaunchKernelGGL((depth_bucket_sort_kernel<0, DS_SMALL, false>), dim3(DS_NB), dim3(256), 0, stream, ds.ranges,
-                           (const uint32_t*)nullptr, ds.pairs, ds.pairs_tmp, idx_passes, geom.means2D, geom.conic_opacity,
-                           radii, geom.sorted_idx, geom.rank_rec);
+                           (const uint32_t*)nullptr, ds.pairs, ds.pairs_tmp, idx_passes, geom.index_rec,
+                           geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
         hipLaunchKernelGGL((depth_bucket_sort_kernel<DS_SMALL, DS_LARGE, true>), dim3(256), dim3(256), 0, stream, ds.ranges,
-                           ds.big_list, ds.pairs, ds.pairs_tmp, idx_passes, geom.means2D, geom.conic_opacity, radii,
-                           geom.sorted_idx, geom.rank_rec);
+                           ds.big_list, ds.pairs, ds.pairs_tmp, idx_passes, geom.index_rec,
+                           geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
     }
     STAGE_CHECK("depth sort");
     const int nwg = bin_workgroups(P);
     const size_t bin_lds = ((size_t)((ntiles + 3) & ~3) + 3 * 1024 + 16) * sizeof(uint32_t);
-    {
-        static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
-        if (!attr_set) {
-            const int max_lds = (int)((BIN_MAX_TILES + 9 * 1024 + 16) * sizeof(uint32_t));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            attr_set = true;
-        }
-    }
     {
         // count pass over rank slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
         StageTimer t(stream, MI_STAGE_TILE_SCAN);
@@ -352,7 +351,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                            img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, stream, ntiles, img.tile_cursor, img.ranges,
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)ntiles + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
                            img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr);
     }
     STAGE_CHECK("tile scan");
@@ -470,8 +469,7 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_CLAMPED] = c.take(p * 3);
     off[MI_GEOM_TILES_TOUCHED] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_DEPTH_KEY] = c.take(p * sizeof(uint32_t));
-    off[MI_GEOM_IDX_IOTA] = c.take(p * sizeof(uint32_t));
-    off[MI_GEOM_SORTED_KEY] = c.take(p * sizeof(uint32_t));
+    off[MI_GEOM_INDEX_REC] = c.take(p * sizeof(BlendRec));
     off[MI_GEOM_SORTED_IDX] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_SORT_TEMP] = c.take(depth_sort_temp_bytes(P) + 16);
     off[MI_GEOM_BWD_PACK] = c.take(p * 8 * sizeof(float));
