@@ -27,8 +27,10 @@ def short(n):
 
 
 STAGE_OF = {"blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd",
-            "preprocess_fwd_kernel": "preprocess", "emit_ranks_kernel": "emit", "tile_sort_kernel": "tile_sort",
-            "tile_scan_kernel": "tile_scan", "geometry_bwd_kernel": "geom_bwd"}
+            "preprocess_fwd_kernel": "preprocess", "bin_ranks_kernel<true>": "emit", "tile_sort_kernel": "tile_sort",
+            "bin_ranks_kernel<false>": "tile_scan", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
+            "depth_bucket_kernel<false>": "depth_sort", "depth_bucket_kernel<true>": "depth_sort",
+            "depth_bucket_sort_kernel": "depth_sort", "geometry_bwd_kernel": "geom_bwd"}
 
 rows = list(csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))))
 agg = {}
@@ -55,7 +57,8 @@ def pmc(name):
         return out
     for r in csv.DictReader(open(path)):
         k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("mirast::", "")
-        k = re.sub(r"<.*", "", k)
+        if not (k.startswith("bin_ranks_kernel") or k.startswith("depth_bucket_kernel")):
+            k = re.sub(r"<.*", "", k)
         out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
