@@ -91,7 +91,7 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
 // ---- 3. tile ranges: exclusive scan of the per-tile totals (single workgroup) ------------------------------
 // Writes ranges[tile] = [base, base+count) (== identifyTileRanges' result, rasterizer_impl.cu:116-138, including
 // {0,0} for empty tiles as left by the reference's cudaMemset), R and the longest list.
-constexpr int RANK_BITS = 28;          // entry = depth rank | (tile may blend) << 28
+constexpr int RANK_BITS = 28;          // entry = depth rank | quadrant mask << 28
 constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 constexpr int BIN_MAX_WG = 512;        // workgroups of the count / emit passes (rank slices)
 constexpr int BIN_THREADS = 1024;
@@ -252,10 +252,9 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
         for_each_tile_balanced(rw, tid, rmin, rmax, count, gx, [&](uint32_t owner, uint32_t tx, uint32_t ty) {
             const uint32_t tile = ty * gx + tx;
             if (EMIT) {
-                // the whole-tile part of the exact-conservative cull (cull.h) is evaluated here, where the record is at
-                // hand, and rides in bit 28 of the entry: the per-tile sort then gathers a record -- and evaluates
-                // the four quadrant tests -- only for the third of the entries that can blend at all
-                const uint32_t qmask = tile_may_blend(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y)) ? 1u : 0u;
+                // the exact-conservative cull (cull.h) is evaluated here, where the record is at hand, and rides in
+                // the top 4 bits of the entry: the per-tile sort then gathers a record only for entries that blend
+                const uint32_t qmask = quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
                 const uint32_t rank = (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
                 const uint32_t slot = atomicAdd(&s_cnt[tile], 1u);
                 entries[slot] = rank | (qmask << RANK_BITS);
@@ -378,11 +377,9 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, int n, ui
                                                 const uint32_t* __restrict__ sorted_idx,
                                                 const BlendRec* __restrict__ rank_rec,
                                                 uint32_t* __restrict__ point_list, BlendRec* __restrict__ blend_rec,
-                                                uint32_t* __restrict__ blend_count, uint32_t tile, uint32_t gx,
-                                                uint32_t* s_wcount)
+                                                uint32_t* __restrict__ blend_count, uint32_t tile, uint32_t* s_wcount)
 {
     const int wave = tid >> 6;
-    const float tile_px = (float)((tile % gx) * TILE_X), tile_py = (float)((tile / gx) * TILE_Y);
     uint32_t* out = point_list + range.x;
     BlendRec* rec = blend_rec + range.x;
     int base = 0;
@@ -393,10 +390,10 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, int n, ui
         if (i < n) {
             const uint32_t e = sorted_entries[i];
             const uint32_t rank = e & RANK_MASK;
+            qmask = e >> RANK_BITS;
             out[i] = sorted_idx[rank];
-            if (e >> RANK_BITS) {
+            if (qmask) {
                 r = rank_rec[rank];
-                qmask = quadrant_mask(r.xy, r.co, tile_px, tile_py);
                 r.pm = ((uint32_t)i << 4) | qmask;
             }
         }
@@ -416,7 +413,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
                                                         const BlendRec* __restrict__ rank_rec,
                                                         uint32_t* __restrict__ point_list, int passes,
                                                         BlendRec* __restrict__ blend_rec,
-                                                        uint32_t* __restrict__ blend_count, uint32_t gx)
+                                                        uint32_t* __restrict__ blend_count)
 {
     __shared__ uint32_t s_a[CAP];
     __shared__ uint32_t s_b[CAP];
@@ -440,7 +437,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
             a = b;
             b = t;
         }
-        emit_tile_lists(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, gx, s_wcount);
+        emit_tile_lists(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
@@ -450,7 +447,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
             a = b;
             b = t;
         }
-        emit_tile_lists(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, gx, s_wcount);
+        emit_tile_lists(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
     }
 }
 

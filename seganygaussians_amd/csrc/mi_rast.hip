@@ -390,7 +390,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             // finished before the emit pass above even started: this wait does not stall the queue.
             hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
                                bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
-                               bin.blend_rec, img.blend_count, vp.grid_x);
+                               bin.blend_rec, img.blend_count);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
             if (g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
@@ -398,11 +398,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             if (max_tile_count > 2048)
                 hipLaunchKernelGGL((tile_sort_kernel<2048, 6144, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
                                    bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
-                                   bin.blend_rec, img.blend_count, vp.grid_x);
+                                   bin.blend_rec, img.blend_count);
             if (max_tile_count > 6144)
                 hipLaunchKernelGGL((tile_sort_kernel<6144, 12288, true>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
                                    bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
-                                   bin.blend_rec, img.blend_count, vp.grid_x);
+                                   bin.blend_rec, img.blend_count);
         }
         STAGE_CHECK("tile sort");
     }
