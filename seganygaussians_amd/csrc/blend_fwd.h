@@ -134,14 +134,16 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
         }
         if (tid < FB && b0 + FB + tid < ns_total) cur = rec[b0 + FB + tid];
         if constexpr (VEC_STAGE) {
-            // ---- B: features (ids straight from the records: thread q reads record q / F4)
+            // ---- B: features, gathered by the ids just staged in LDS (a second trip to the records in memory
+            // would put one more ~4 us dependent access in front of every batch)
+            __syncthreads();
             constexpr int F4 = C / 4;  // float4s per Gaussian
             if (!(ablate & 4))
 #pragma unroll
             for (int k = 0; k < FB * F4 / BATCH; k++) {
                 const int q = tid + BATCH * k;
                 const int g = q / F4, part = q % F4;
-                if (g < nb) s_feat4[g * F4 + part] = reinterpret_cast<const float4*>(features + (size_t)rec[b0 + g].id * C)[part];
+                if (g < nb) s_feat4[g * F4 + part] = reinterpret_cast<const float4*>(features + (size_t)s_id[g] * C)[part];
             }
         }
         __syncthreads();
