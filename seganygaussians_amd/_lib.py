@@ -20,6 +20,7 @@ EXPORTS = [
     "mi_rast_mask_backward", "mi_rast_last_error", "mi_rast_version", "mi_rast_supported_channels",
     "mi_rast_get_higher_msb", "mi_rast_geometry_layout", "mi_rast_image_layout", "mi_rast_binning_layout",
     "mi_rast_profile_enable", "mi_rast_profile_read",
+    "mi_knn_smooth_forward", "mi_knn_smooth_backward",  # include/mi_knn_smooth.h
 ]
 
 _lib = None
@@ -73,6 +74,11 @@ def load():
     L.mi_rast_profile_enable.argtypes = [i]
     L.mi_rast_profile_read.restype = i
     L.mi_rast_profile_read.argtypes = [C.POINTER(f)]
+    u32 = C.c_uint32
+    L.mi_knn_smooth_forward.restype = i
+    L.mi_knn_smooth_forward.argtypes = [i, i, i, vp, u32, vp, vp, i, vp]
+    L.mi_knn_smooth_backward.restype = i
+    L.mi_knn_smooth_backward.argtypes = [i, i, i, vp, vp, vp, u32, vp, vp, vp, vp, i, vp]
     _lib = L
     return L
 

