@@ -198,3 +198,39 @@ def test_full_size_cfg3_properties():
     lhs = float((f1.cpu().double().numpy() * grads["dL_dcolors"].astype(np.float64)).sum())
     rhs = float((gpu.color.cpu().double().numpy() * dL.astype(np.float64)).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(abs(rhs), 1e-9) + 1e-9, (lhs, rhs)
+
+
+def _max_tile_list(gpu):
+    r = gpu.img_fields()["ranges"].reshape(-1, 2).astype(np.int64)
+    return int((r[:, 1] - r[:, 0]).max())
+
+
+def test_depth_ties_dense_layers():
+    """Thousands of Gaussians at EXACTLY the same depth (front camera: view z == world z): the (depth, index) order
+    must come out of the bucketed depth ordering bit-exactly -- one bucket of 6000 pairs (LDS radix path), then a
+    bucket of 12000 (> 8192: HBM ping-pong path) next to a 1-ulp neighbour layer and a far layer."""
+    inp = hp.make_inputs(6000, 256, 160, 3, seed=11, log_scale=math.log(0.01), log_scale_std=0.3)
+    inp.means3D = np.ascontiguousarray(inp.means3D, np.float32)
+    inp.means3D[:, 2] = 4.0
+    _fwd_bwd(inp)
+    inp = hp.make_inputs(20000, 256, 160, 3, seed=12, log_scale=math.log(0.008), log_scale_std=0.3)
+    m = np.ascontiguousarray(inp.means3D, np.float32)
+    m[:12000, 2] = 3.0
+    m[12000:16000, 2] = np.nextafter(np.float32(3.0), np.float32(4.0))
+    m[16000:, 2] = 5.0
+    rng = np.random.default_rng(5)
+    inp.means3D = m[rng.permutation(20000)]          # layers interleaved in index order
+    _fwd_bwd(inp)
+
+
+def test_long_tile_lists_all_sort_classes():
+    """Tile lists beyond 2048, 6144 and 12288 entries: the three size classes of the per-tile sort, including the one
+    that ping-pongs through HBM."""
+    inp = hp.make_inputs(90_000, 96, 64, 3, seed=13, focal=40.0, log_scale=math.log(0.25), log_scale_std=0.4,
+                         z_range=(2.0, 9.0))
+    rep, gpu, fwd = _fwd_bwd(inp)
+    assert _max_tile_list(gpu) > 12288, _max_tile_list(gpu)
+    inp = hp.make_inputs(20_000, 96, 64, 3, seed=14, focal=40.0, log_scale=math.log(0.2), log_scale_std=0.4,
+                         z_range=(2.0, 9.0))
+    rep, gpu, fwd = _fwd_bwd(inp)
+    assert 2048 < _max_tile_list(gpu) <= 12288, _max_tile_list(gpu)
