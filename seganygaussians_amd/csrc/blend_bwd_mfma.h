@@ -1,4 +1,4 @@
-// blend_bwd_mfma.h -- per-tile back-to-front gradient pass for C = 32 feature channels on the matrix pipe.
+// blend_bwd_mfma.h -- per-tile back-to-front gradient pass for C = 32 / 64 feature channels with f32 MFMA.
 //
 // Same mathematics as blend_bwd.h (which restates renderCUDA<C> backward, CF/cuda_rasterizer/backward.cu:399-559,
 // and remains the path for C = 3 / 64 and the mask variants); same tolerance-checked results.  What changes is
@@ -25,22 +25,25 @@
 #include "blend_fwd.h"
 #include "common.h"
 
-#ifndef BWD_WAVES_PER_SIMD
-#define BWD_WAVES_PER_SIMD 3
-#endif
-
 namespace mirast {
 
-constexpr int RB2 = 80;    // blend-list records per batch (LDS budget of 3 workgroups per CU)
-constexpr int FROW = 36;   // padded feature row (floats): conflict-free 16-lane b128 operand reads
 constexpr int WROW = 68;   // padded w/u row (floats)
 constexpr int CHK = 16;    // rows per MFMA chunk
-constexpr int DLROW = 33;  // padded gradient-image staging row (floats)
-constexpr int NBITS = (RB2 + 63) / 64;
-constexpr int FEAT4 = (RB2 + 1) * FROW / 4;  // + one all-zero row for the list padding
-constexpr int POOL4 = FEAT4 + 2 * 4 * CHK * WROW / 4;
-static_assert(POOL4 * 4 >= 4 * 64 * DLROW, "gradient-image staging must fit in the aliased buffers");
-static_assert(RB2 + FROW / 4 <= 256, "staging roles are assigned by thread index");
+constexpr int DLROW = 33;  // padded gradient-image staging row (floats; 32 channels at a time)
+
+// Per channel count: blend-list records per batch (LDS budget of 3 workgroups per CU at C = 32, 2 at C = 64),
+// padded feature row (floats; conflict-free 16-lane b128 operand reads), waves per SIMD the registers allow.
+template <int C>
+struct BwdCfg {
+    static constexpr int RB2 = C == 32 ? 80 : 128;
+    static constexpr int FROW = C + 4;
+    static constexpr int NBITS = (RB2 + 63) / 64;
+    static constexpr int FEAT4 = (RB2 + 1) * FROW / 4;  // + one all-zero row for the list padding
+    static constexpr int POOL4 = FEAT4 + 2 * 4 * CHK * WROW / 4;
+    static constexpr int WAVES = C == 32 ? 3 : 2;
+    static_assert(POOL4 * 4 >= 4 * 64 * DLROW, "gradient-image staging must fit in the aliased buffers");
+    static_assert(RB2 + FROW / 4 <= 256, "staging roles are assigned by thread index");
+};
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -54,14 +57,19 @@ struct BwdPar {
 // for its full 32 cycles (tools/valu_rate_probe.hip, tools/interleave_probe.hip, tools/overlap_probe.hip).  Hence:
 // few instructions per (row, pixel), row parameters fetched by LDS broadcast reads (not VALU), no selects where
 // arithmetic with alpha = 0 does the same, and the register budget of 3 waves per SIMD.
-__global__ void __launch_bounds__(256, BWD_WAVES_PER_SIMD) blend_bwd32_mfma_kernel(
+template <int C>
+__global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
     int W, int H, const float* __restrict__ bg_color, const float* __restrict__ colors,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     float* __restrict__ gpack /*[P,8] packed field gradients*/, float* __restrict__ dL_dcolors,
     int ablate /* timing experiments only; 0 in production */)
 {
-    constexpr int C = 32;
+    constexpr int RB2 = BwdCfg<C>::RB2, FROW = BwdCfg<C>::FROW, NBITS = BwdCfg<C>::NBITS, FEAT4 = BwdCfg<C>::FEAT4;
+    constexpr int POOL4 = BwdCfg<C>::POOL4;
+    constexpr int CPL = C / 4;   // channels per lane in the S contraction: lane (n16, kq) holds channels CPL*kq .. +CPL-1
+    constexpr int NB = C / 16;   // 16-channel blocks of the dF contraction
+    constexpr int F4 = C / 4;    // float4s per feature row
     __shared__ BwdPar s_par[RB2 + 1];                // [RB2] = padding record (never valid)
     __shared__ float4 s_pool[POOL4];                 // feature rows | w rows | u rows  (prologue: gradient-image staging)
     __shared__ uint64_t s_bits[4][NBITS];
@@ -110,27 +118,41 @@ __global__ void __launch_bounds__(256, BWD_WAVES_PER_SIMD) blend_bwd32_mfma_kern
     // the two MFMA operand layouts.  The staging rows alias the feature / w / u buffers, which are first written
     // after the barrier that opens the batch loop.
     const int n16 = lane & 15, kq = lane >> 4;
-    float dLB[4][8];   // B of the S contraction:  dLB[pb][s] = dL[pixel 16*pb + n16][channel 8*kq + s]
-    float dLT[2][16];  // B of the dF contraction: dLT[nb][s] = dL[pixel 16*kq + s][channel 16*nb + n16]
+    float dLB[4][CPL];  // B of the S contraction:  dLB[pb][s] = dL[pixel 16*pb + n16][channel CPL*kq + s]
+    float dLT[NB][16];  // B of the dF contraction: dLT[nb][s] = dL[pixel 16*kq + s][channel 16*nb + n16]
     float bg_dot_dpixel = 0.f;  // bg . dL of this lane's own pixel (backward.cu:533-535)
     {
         float* stage = reinterpret_cast<float*>(s_pool) + wave * (64 * DLROW);
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) {
-            const float v = inside ? dLpix[ch] : 0.f;
-            bg_dot_dpixel += bg_color[ch] * v;
-            stage[lane * DLROW + ch] = v;
+        for (int h = 0; h < C / 32; h++) {  // 32 channels per pass through the staging rows
+#pragma unroll
+            for (int c = 0; c < 32; c++) {
+                const float v = inside ? dLpix[32 * h + c] : 0.f;
+                bg_dot_dpixel += bg_color[32 * h + c] * v;
+                stage[lane * DLROW + c] = v;
+            }
+            if (h == 0) {
+                __syncthreads();  // also publishes s_Lt
+                if (max(max(s_Lt[0], s_Lt[1]), max(s_Lt[2], s_Lt[3])) == 0) return;
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+            // lanes whose CPL channels lie in this pass (all of them when C == 32)
+            const bool mine = (CPL * kq) / 32 == h;
+            const int c0 = (CPL * kq) % 32;
+#pragma unroll
+            for (int pb = 0; pb < 4; pb++)
+#pragma unroll
+                for (int s = 0; s < CPL; s++) {
+                    const float v = stage[(16 * pb + n16) * DLROW + (mine ? c0 + s : s)];
+                    if (C == 32 || mine) dLB[pb][s] = v;
+                }
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) dLT[2 * h + nb][s] = stage[(16 * kq + s) * DLROW + 16 * nb + n16];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
-        __syncthreads();  // also publishes s_Lt
-        if (max(max(s_Lt[0], s_Lt[1]), max(s_Lt[2], s_Lt[3])) == 0) return;
-#pragma unroll
-        for (int pb = 0; pb < 4; pb++)
-#pragma unroll
-            for (int s = 0; s < 8; s++) dLB[pb][s] = stage[(16 * pb + n16) * DLROW + 8 * kq + s];
-#pragma unroll
-        for (int s = 0; s < 16; s++)
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) dLT[nb][s] = stage[(16 * kq + s) * DLROW + 16 * nb + n16];
     }
     TK(1);
     const float nTb = -T_final * bg_dot_dpixel;  // the background term of dL/dalpha is nTb / (1 - alpha)
@@ -186,9 +208,9 @@ __global__ void __launch_bounds__(256, BWD_WAVES_PER_SIMD) blend_bwd32_mfma_kern
         __syncthreads();
         // ---- B: feature rows (padded to FROW floats), gathered by the ids just staged
 #pragma unroll
-        for (int k = 0; k < (RB2 * 8 + BATCH - 1) / BATCH; k++) {
+        for (int k = 0; k < (RB2 * F4 + BATCH - 1) / BATCH; k++) {
             const int e = tid + BATCH * k;
-            const int g = e >> 3, part = e & 7;
+            const int g = e / F4, part = e % F4;
             if (g < nr && !(ablate & 4))
                 s_feat4[g * (FROW / 4) + part] = reinterpret_cast<const float4*>(colors + (size_t)__float_as_int(s_par[g].q1.w) * C)[part];
         }
@@ -217,13 +239,19 @@ __global__ void __launch_bounds__(256, BWD_WAVES_PER_SIMD) blend_bwd32_mfma_kern
             v4f sacc[4];
             {
                 const uint32_t km = my_off / (uint32_t)sizeof(BwdPar);
-                const float4 fa0 = s_feat4[km * (FROW / 4) + 2 * kq];
-                const float4 fa1 = s_feat4[km * (FROW / 4) + 2 * kq + 1];
-                const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
+                float fa[CPL];
+#pragma unroll
+                for (int q = 0; q < CPL / 4; q++) {
+                    const float4 f = s_feat4[km * (FROW / 4) + (CPL / 4) * kq + q];
+                    fa[4 * q + 0] = f.x;
+                    fa[4 * q + 1] = f.y;
+                    fa[4 * q + 2] = f.z;
+                    fa[4 * q + 3] = f.w;
+                }
 #pragma unroll
                 for (int pb = 0; pb < 4; pb++) sacc[pb] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 8; s++)
+                for (int s = 0; s < CPL; s++)
 #pragma unroll
                     for (int pb = 0; pb < 4; pb++)
                         sacc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], dLB[pb][s], sacc[pb], 0, 0, 0);
@@ -276,7 +304,9 @@ __global__ void __launch_bounds__(256, BWD_WAVES_PER_SIMD) blend_bwd32_mfma_kern
             if (rowmask == 0 || (ablate & 2)) continue;
 
             // ---- 3. dF = W^T . dL  and  M = U^T . Phi   (A rows from LDS, lane (m = n16, kq) reads pixels 16kq..16kq+15)
-            v4f facc[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
+            v4f facc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) facc[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
             v4f macc = (v4f){0.f, 0.f, 0.f, 0.f};
             {
                 const float4* wrow = reinterpret_cast<const float4*>(my_wa + n16 * WROW + 16 * kq);
@@ -290,8 +320,9 @@ __global__ void __launch_bounds__(256, BWD_WAVES_PER_SIMD) blend_bwd32_mfma_kern
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const int s = 4 * s4 + t;
-                        facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[0][s], facc[0], 0, 0, 0);
-                        facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[1][s], facc[1], 0, 0, 0);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++)
+                            facc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[nb][s], facc[nb], 0, 0, 0);
                         const float x = (float)(s & 7) - 3.5f;
                         const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
                         macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
@@ -307,8 +338,8 @@ __global__ void __launch_bounds__(256, BWD_WAVES_PER_SIMD) blend_bwd32_mfma_kern
                 const bool act = (rowmask >> row) & 1u;
                 const uint32_t gid = (uint32_t)__shfl(my_gid, row, 64);
                 if (act && !(ablate & 64)) {
-                    atomicAdd(&dL_dcolors[(size_t)gid * C + n16], facc[0][r]);
-                    atomicAdd(&dL_dcolors[(size_t)gid * C + 16 + n16], facc[1][r]);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) atomicAdd(&dL_dcolors[(size_t)gid * C + 16 * nb + n16], facc[nb][r]);
                 }
                 if (n16 < 8) my_mom[row * 8 + n16] = macc[r];
             }

@@ -654,7 +654,11 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor);
         else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
         else if (channels == 32 && !(g_ablate & 1024))
-            hipLaunchKernelGGL(blend_bwd32_mfma_kernel, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+            hipLaunchKernelGGL(blend_bwd_mfma_kernel<32>, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+                               bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib,
+                               dL_dpix, geom.bwd_pack, dL_dcolor, g_ablate);
+        else if (channels == 64 && !(g_ablate & 1024))
+            hipLaunchKernelGGL(blend_bwd_mfma_kernel<64>, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
                                bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib,
                                dL_dpix, geom.bwd_pack, dL_dcolor, g_ablate);
         else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
