@@ -297,20 +297,20 @@ __global__ void __launch_bounds__(1024) scan_partials_kernel(int ntiles, int nwg
 }
 
 // ---- 5. per-tile LDS radix sort of the ranks --------------------------------------------------------
-// One 256-thread workgroup per tile; handles tiles with LO < n <= CAP in LDS; when GLOBAL_FALLBACK is set it
+// One workgroup (256 threads for short lists, 1024 for long ones) per tile; handles tiles with LO < n <= CAP in LDS; when GLOBAL_FALLBACK is set it
 // also handles n > CAP by ping-ponging between `entries` and `scratch` in HBM with the same code.
 // LSD radix, 8-bit digits, `passes` = ceil(rank_bits / 8).  Each wave owns a contiguous quarter of the tile's
 // list; per pass: per-wave digit histograms -> workgroup scan over (digit, wave) -> each wave scatters its quarter
 // 64 keys at a time with a stable ballot-match rank.  Three workgroup barriers per pass.
-template <typename SrcPtr, typename DstPtr>
+template <int NW, typename SrcPtr, typename DstPtr>
 __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int shift, uint32_t (*s_hist)[256], int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    // contiguous quarter per wave, in multiples of 64 keys
+    // contiguous share per wave (NW waves), in multiples of 64 keys
     const int chunks = (n + 63) >> 6;
-    const int cpw = (chunks + 3) >> 2;
+    const int cpw = (chunks + NW - 1) / NW;
     const int begin = min(n, wave * cpw * 64), end = min(n, (wave + 1) * cpw * 64);
-    for (int d = tid; d < 4 * 256; d += 256) (&s_hist[0][0])[d] = 0;
+    for (int d = tid; d < NW * 256; d += NW * 64) (&s_hist[0][0])[d] = 0;
     __syncthreads();
 
     auto match = [&](uint32_t digit, bool active, uint32_t& rank_in_wave, uint32_t& cnt) {
@@ -335,22 +335,29 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
         if (active && rk == 0) s_hist[wave][digit] += cnt;  // one lane per distinct digit, wave-private row
     }
     __syncthreads();
-    // (b) exclusive scan over (digit major, wave minor): thread d owns digit d
+    // (b) exclusive scan over (digit major, wave minor): thread d < 256 owns digit d
     {
-        const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid], c3 = s_hist[3][tid];
-        const uint32_t tot = c0 + c1 + c2 + c3;
-        // workgroup exclusive scan of tot over 256 threads
         __shared__ uint32_t s_wsum[4];
-        const uint32_t incl = wave_inclusive_scan(tot, lane);
-        if (lane == 63) s_wsum[wave] = incl;
+        uint32_t tot = 0, incl = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) tot += s_hist[w][tid];
+            // workgroup exclusive scan of tot over the 256 digit threads
+            incl = wave_inclusive_scan(tot, lane);
+            if (lane == 63) s_wsum[wave] = incl;
+        }
         __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += s_wsum[w];
-        const uint32_t excl = woff + incl - tot;
-        s_hist[0][tid] = excl;
-        s_hist[1][tid] = excl + c0;
-        s_hist[2][tid] = excl + c0 + c1;
-        s_hist[3][tid] = excl + c0 + c1 + c2;
+        if (tid < 256) {
+            uint32_t woff = 0;
+            for (int w = 0; w < wave; w++) woff += s_wsum[w];
+            uint32_t run = woff + incl - tot;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const uint32_t c = s_hist[w][tid];
+                s_hist[w][tid] = run;
+                run += c;
+            }
+        }
     }
     __syncthreads();
     // (c) stable scatter of this wave's quarter; s_hist[wave][digit] is now this wave's running cursor
@@ -372,7 +379,7 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
 
 // Emits point_list (the reference-exact sorted id list) and, in the same pass, the compacted blend list of the
 // tile: entries whose quadrant mask is non-zero, in list order, at blend_rec[range.x ...], count in blend_count.
-template <typename SrcPtr>
+template <int NW, typename SrcPtr>
 __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, int n, uint2 range, int tid,
                                                 const uint32_t* __restrict__ sorted_idx,
                                                 const BlendRec* __restrict__ rank_rec,
@@ -383,7 +390,7 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, int n, ui
     uint32_t* out = point_list + range.x;
     BlendRec* rec = blend_rec + range.x;
     int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 256) {
+    for (int i0 = 0; i0 < n; i0 += NW * 64) {
         const int i = i0 + tid;
         uint32_t qmask = 0;
         BlendRec r;
@@ -398,7 +405,7 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, int n, ui
             }
         }
         int ns;
-        const int slot = compact_slot(qmask != 0, wave, s_wcount, ns);
+        const int slot = compact_slot<NW>(qmask != 0, wave, s_wcount, ns);
         if (slot >= 0) rec[base + slot] = r;
         base += ns;
         __syncthreads();  // s_wcount reuse
@@ -406,8 +413,8 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, int n, ui
     if (tid == 0) blend_count[tile] = (uint32_t)base;
 }
 
-template <int LO, int CAP, bool GLOBAL_FALLBACK>
-__global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ entries,
+template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT>
+__global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ entries,
                                                         uint32_t* __restrict__ scratch,
                                                         const uint32_t* __restrict__ sorted_idx,
                                                         const BlendRec* __restrict__ rank_rec,
@@ -417,8 +424,9 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
 {
     __shared__ uint32_t s_a[CAP];
     __shared__ uint32_t s_b[CAP];
-    __shared__ uint32_t s_hist[4][256];
-    __shared__ uint32_t s_wcount[4];
+    constexpr int NW = NT / 64;
+    __shared__ uint32_t s_hist[NW][256];
+    __shared__ uint32_t s_wcount[NW];
     const int tid = threadIdx.x;
     const uint2 range = ranges[blockIdx.x];
     const int n = (int)(range.y - range.x);
@@ -427,27 +435,27 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
     if (n > CAP && !GLOBAL_FALLBACK) return;
     uint32_t* seg = entries + range.x;
     if (n <= CAP) {
-        for (int i = tid; i < n; i += 256) s_a[i] = seg[i];
+        for (int i = tid; i < n; i += NT) s_a[i] = seg[i];
         __syncthreads();
         uint32_t* a = s_a;
         uint32_t* b = s_b;
         for (int p = 0; p < passes; p++) {
-            radix_pass(a, b, n, 8 * p, s_hist, tid);
+            radix_pass<NW>(a, b, n, 8 * p, s_hist, tid);
             uint32_t* t = a;
             a = b;
             b = t;
         }
-        emit_tile_lists(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
+        emit_tile_lists<NW>(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
         for (int p = 0; p < passes; p++) {
-            radix_pass(a, b, n, 8 * p, s_hist, tid);
+            radix_pass<NW>(a, b, n, 8 * p, s_hist, tid);
             uint32_t* t = a;
             a = b;
             b = t;
         }
-        emit_tile_lists(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
+        emit_tile_lists<NW>(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
     }
 }
 

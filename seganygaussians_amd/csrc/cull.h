@@ -74,16 +74,22 @@ __device__ __forceinline__ uint32_t quadrant_mask(float2 xy, float4 co, float ti
 }
 
 // Order-preserving compaction of one batch: returns this thread's slot (or -1) and the survivor count.
-// s_wcount: LDS uint32[4].  Contains one workgroup barrier.
+// s_wcount: LDS uint32[NW] (NW waves in the workgroup).  Contains one workgroup barrier.
+template <int NW = 4>
 __device__ __forceinline__ int compact_slot(bool survive, int wave, uint32_t* s_wcount, int& total)
 {
     const uint64_t b = ballot64(survive);
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
     if ((threadIdx.x & 63) == 0) s_wcount[wave] = (uint32_t)__builtin_popcountll(b);
     __syncthreads();
-    const uint32_t c0 = s_wcount[0], c1 = s_wcount[1], c2 = s_wcount[2], c3 = s_wcount[3];
-    total = (int)(c0 + c1 + c2 + c3);
-    const uint32_t woff = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t c = s_wcount[w];
+        woff += w < wave ? c : 0u;
+        tot += c;
+    }
+    total = (int)tot;
     return survive ? (int)(woff + below) : -1;
 }
 

@@ -387,10 +387,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         if (g_ablate_fwd & 256) passes = 0;  // timing experiment: skip the radix passes (wrong order)
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
-            // three list-length classes (LDS footprint 20 / 52 / 100 KB per workgroup); a class is launched only if
+            // three list-length classes (256 threads + 20 KB of LDS, 1024 threads + 64 KB, 1024 threads + 112 KB); a class is launched only if
             // some tile needs it.  The longest list was copied to the host right after the range scan, which
             // finished before the emit pass above even started: this wait does not stall the queue.
-            hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
+            hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false, 256>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
                                bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
                                bin.blend_rec, img.blend_count);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
@@ -398,11 +398,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
             if (max_tile_count > 2048)
-                hipLaunchKernelGGL((tile_sort_kernel<2048, 6144, false>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
+                hipLaunchKernelGGL((tile_sort_kernel<2048, 6144, false, 1024>), dim3(ntiles), dim3(1024), 0, stream, img.ranges,
                                    bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
                                    bin.blend_rec, img.blend_count);
             if (max_tile_count > 6144)
-                hipLaunchKernelGGL((tile_sort_kernel<6144, 12288, true>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
+                hipLaunchKernelGGL((tile_sort_kernel<6144, 12288, true, 1024>), dim3(ntiles), dim3(1024), 0, stream, img.ranges,
                                    bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
                                    bin.blend_rec, img.blend_count);
         }
