@@ -377,40 +377,65 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
     __syncthreads();
 }
 
-// Emits point_list (the reference-exact sorted id list) and, in the same pass, the compacted blend list of the
-// tile: entries whose quadrant mask is non-zero, in list order, at blend_rec[range.x ...], count in blend_count.
-template <int NW, typename SrcPtr>
-__device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, int n, uint2 range, int tid,
+// Emits point_list (the reference-exact sorted id list) and the compacted blend list of the tile: entries whose
+// quadrant mask is non-zero, in list order, at blend_rec[range.x ...], count in blend_count.
+// Latency is what this phase is made of (two dependent gathers per entry), so no workgroup barrier sits between
+// consecutive loads: every wave owns a contiguous share of the sorted list; pass 1 writes point_list and counts the
+// wave's survivors, one barrier exchanges the counts, pass 2 lists the survivors' positions in `spare` (order
+// preserved: shares are contiguous), and pass 3 gathers the 32-byte records of the survivors on dense lanes.
+template <int NW, typename SrcPtr, typename SparePtr>
+__device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, SparePtr spare, int n, uint2 range, int tid,
                                                 const uint32_t* __restrict__ sorted_idx,
                                                 const BlendRec* __restrict__ rank_rec,
                                                 uint32_t* __restrict__ point_list, BlendRec* __restrict__ blend_rec,
                                                 uint32_t* __restrict__ blend_count, uint32_t tile, uint32_t* s_wcount)
 {
-    const int wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     uint32_t* out = point_list + range.x;
     BlendRec* rec = blend_rec + range.x;
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += NW * 64) {
-        const int i = i0 + tid;
-        uint32_t qmask = 0;
-        BlendRec r;
-        if (i < n) {
+    const int chunks = (n + 63) >> 6;
+    const int cpw = (chunks + NW - 1) / NW;
+    const int begin = min(n, wave * cpw * 64), end = min(n, (wave + 1) * cpw * 64);
+    // pass 1: point_list; survivors of this wave's share
+    uint32_t mine = 0;
+    for (int i0 = begin; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t keep = 0;
+        if (i < end) {
             const uint32_t e = sorted_entries[i];
-            const uint32_t rank = e & RANK_MASK;
-            qmask = e >> RANK_BITS;
-            out[i] = sorted_idx[rank];
-            if (qmask) {
-                r = rank_rec[rank];
-                r.pm = ((uint32_t)i << 4) | qmask;
-            }
+            out[i] = sorted_idx[e & RANK_MASK];
+            keep = (e >> RANK_BITS) != 0u;
         }
-        int ns;
-        const int slot = compact_slot<NW>(qmask != 0, wave, s_wcount, ns);
-        if (slot >= 0) rec[base + slot] = r;
-        base += ns;
-        __syncthreads();  // s_wcount reuse
+        mine += (uint32_t)__builtin_popcountll(ballot64(keep != 0u));
     }
-    if (tid == 0) blend_count[tile] = (uint32_t)base;
+    if (lane == 0) s_wcount[wave] = mine;
+    __syncthreads();
+    uint32_t base = 0, ns = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t c = s_wcount[w];
+        base += w < wave ? c : 0u;
+        ns += c;
+    }
+    // pass 2: positions of the survivors, in list order
+    for (int i0 = begin; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const bool keep = i < end && ((uint32_t)sorted_entries[i] >> RANK_BITS) != 0u;
+        const uint64_t bal = ballot64(keep);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (keep) spare[base + below] = (uint32_t)i;
+        base += (uint32_t)__builtin_popcountll(bal);
+    }
+    __syncthreads();
+    // pass 3: records of the survivors (dense, no barriers: the gathers of successive iterations overlap)
+    for (int j = tid; j < (int)ns; j += NW * 64) {
+        const uint32_t i = spare[j];
+        const uint32_t e = sorted_entries[i];
+        BlendRec r = rank_rec[e & RANK_MASK];
+        r.pm = (i << 4) | (e >> RANK_BITS);
+        rec[j] = r;
+    }
+    if (tid == 0) blend_count[tile] = ns;
 }
 
 template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT>
@@ -445,7 +470,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__
             a = b;
             b = t;
         }
-        emit_tile_lists<NW>(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
+        emit_tile_lists<NW>(a, b, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
@@ -455,7 +480,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__
             a = b;
             b = t;
         }
-        emit_tile_lists<NW>(a, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
+        emit_tile_lists<NW>(a, b, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
     }
 }
 
