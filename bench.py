@@ -55,8 +55,8 @@ def algorithmic_bytes(c, C):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg3", help="cfg3 (default, headline) | cfg5 | cfg1")
     ap.add_argument("--points", type=int, default=None, help="override Gaussian count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

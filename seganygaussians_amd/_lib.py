@@ -35,6 +35,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime; load it first so that this library binds to the same one (loading
+    # /opt/rocm's copy first leaves the process with a runtime that sees no device once torch initialises its own)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MiRastError(
             f"HIP extension {LIB_PATH} is missing. Build it with `python -m seganygaussians_amd.build` "
