@@ -48,10 +48,14 @@ struct RectWork {
     uint32_t* wsum;    // LDS [16]
 };
 
-// Contains workgroup barriers: call from all 1024 threads.  f(owner_thread, tile_x, tile_y).
-template <typename F>
+// Contains workgroup barriers: call from all 1024 threads.
+// f1(owner_thread, tile_x, tile_y) handles an item or returns true to DEFER it; deferred items collect in a per-wave
+// LDS queue (ballot-prefix positions, wave-synchronous: no barrier) and are handed to f2 sixty-four at a time, i.e.
+// on dense lanes.  With DEFER = false, f1's return value is ignored and f2 is never called.
+template <bool DEFER, typename F1, typename F2>
 __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int tid, uint2 rmin, uint2 rmax, uint32_t count,
-                                                       uint32_t gx, F&& f)
+                                                       uint32_t* wave_queue /* LDS [128] per wave when DEFER */, F1&& f1,
+                                                       F2&& f2)
 {
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t incl = wave_inclusive_scan(count, lane);
@@ -69,21 +73,53 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
     rw.rx[tid] = rmin.x | ((rmax.x - rmin.x) << 16);
     rw.ry[tid] = rmin.y;
     __syncthreads();
-    for (uint32_t k = tid; k < total; k += 1024) {
-        // first thread o with prefix[o] > k
-        int lo = 0;
+    uint32_t queued = 0;  // wave-uniform
+    const uint32_t wave_items_end = total;
+    for (uint32_t k0 = (uint32_t)(tid - lane); k0 < wave_items_end; k0 += 1024) {  // wave-uniform trip count
+        const uint32_t k = k0 + (uint32_t)lane;
+        bool defer = false;
+        uint32_t item = 0;
+        if (k < total) {
+            // first thread o with prefix[o] > k
+            int lo = 0;
 #pragma unroll
-        for (int step = 512; step >= 1; step >>= 1)
-            if (rw.prefix[lo + step - 1] <= k) lo += step;
-        const uint32_t packed = rw.rx[lo];
-        const uint32_t w = packed >> 16, x0 = packed & 0xFFFFu, y0 = rw.ry[lo];
-        const uint32_t prev = lo == 0 ? 0u : rw.prefix[lo - 1];
-        const uint32_t i = k - prev;
-        // row = i / w without an integer divide: (i + 0.5) / w is never within float error of an integer
-        // boundary for i < 2^14 * w (a Gaussian covers at most grid_x * grid_y tiles)
-        const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w));
-        const uint32_t col = i - row * w;
-        f((uint32_t)lo, x0 + col, y0 + row);
+            for (int step = 512; step >= 1; step >>= 1)
+                if (rw.prefix[lo + step - 1] <= k) lo += step;
+            const uint32_t packed = rw.rx[lo];
+            const uint32_t w = packed >> 16, x0 = packed & 0xFFFFu, y0 = rw.ry[lo];
+            const uint32_t prev = lo == 0 ? 0u : rw.prefix[lo - 1];
+            const uint32_t i = k - prev;
+            // row = i / w without an integer divide: (i + 0.5) / w is never within float error of an integer
+            // boundary for i < 2^14 * w (a Gaussian covers at most grid_x * grid_y tiles)
+            const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+            const uint32_t col = i - row * w;
+            const uint32_t tx = x0 + col, ty = y0 + row;
+            defer = f1((uint32_t)lo, tx, ty);
+            item = (uint32_t)lo | (tx << 10) | (ty << 21);
+        }
+        if (!DEFER) continue;
+        const uint64_t bal = ballot64(defer);
+        if (bal != 0) {
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (defer) wave_queue[queued + below] = item;
+            queued += (uint32_t)__builtin_popcountll(bal);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (queued >= 64u) {
+                const uint32_t e = wave_queue[lane];
+                const uint32_t spill = wave_queue[64 + lane];  // entries 64 .. queued-1 move down afterwards
+                f2(e & 0x3FFu, (e >> 10) & 0x7FFu, e >> 21);
+                queued -= 64u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if ((uint32_t)lane < queued) wave_queue[lane] = spill;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        }
+    }
+    if (DEFER && queued != 0) {
+        if ((uint32_t)lane < queued) {
+            const uint32_t e = wave_queue[lane];
+            f2(e & 0x3FFu, (e >> 10) & 0x7FFu, e >> 21);
+        }
     }
     __syncthreads();  // LDS hand-off arrays are reused by the next call
 }
@@ -95,7 +131,7 @@ constexpr int RANK_BITS = 28;          // entry = depth rank | quadrant mask << 
 constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 constexpr int BIN_MAX_WG = 512;        // workgroups of the count / emit passes (rank slices)
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_TILES = 31 * 1024 - 64;  // LDS: one counter per tile + 37 KB of hand-off arrays must fit in 160 KB
+constexpr int BIN_MAX_TILES = 29 * 1024 - 64;  // LDS: one counter per tile + 45 KB of hand-off arrays must fit in 160 KB
 
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
@@ -226,6 +262,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
     RectWork rw{s_rw, s_rw + 1024, s_rw + 2048, s_rw + 3072};
     float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);          // EMIT only: the owners' means ...
     float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);   // ... and conics + opacities
+    uint32_t* s_queue = s_rw + 3088 + 6144;                         // ... and 128 deferred items per wave
     uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles;
     for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = EMIT ? ranges[t].x + my_partial[t] : 0u;
     __syncthreads();
@@ -249,19 +286,36 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
                 s_co[tid] = rec.co;
             }
         }
-        for_each_tile_balanced(rw, tid, rmin, rmax, count, gx, [&](uint32_t owner, uint32_t tx, uint32_t ty) {
-            const uint32_t tile = ty * gx + tx;
-            if (EMIT) {
-                // the exact-conservative cull (cull.h) is evaluated here, where the record is at hand, and rides in
-                // the top 4 bits of the entry: the per-tile sort then gathers a record only for entries that blend
-                const uint32_t qmask = quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
-                const uint32_t rank = (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
-                const uint32_t slot = atomicAdd(&s_cnt[tile], 1u);
-                entries[slot] = rank | (qmask << RANK_BITS);
-            } else {
-                atomicAdd(&s_cnt[tile], 1u);
-            }
-        });
+        auto rank_of = [&](uint32_t owner) {
+            return (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
+        };
+        if (EMIT) {
+            // The exact-conservative cull (cull.h) is evaluated here, where the record is at hand, and its quadrant mask
+            // rides in the top 4 bits of the entry: the per-tile sort then gathers a record only for entries that blend.
+            // The whole-tile test runs on every overlap (two thirds end there with mask 0); the four quadrant tests of
+            // the rest run on dense lanes, 64 deferred overlaps at a time.
+            for_each_tile_balanced<true>(
+                rw, tid, rmin, rmax, count, s_queue + wave * 128,
+                [&](uint32_t owner, uint32_t tx, uint32_t ty) {
+                    if (tile_may_blend(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y))) return true;
+                    const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
+                    entries[slot] = rank_of(owner);
+                    return false;
+                },
+                [&](uint32_t owner, uint32_t tx, uint32_t ty) {
+                    const uint32_t qmask = quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
+                    const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
+                    entries[slot] = rank_of(owner) | (qmask << RANK_BITS);
+                });
+        } else {
+            for_each_tile_balanced<false>(
+                rw, tid, rmin, rmax, count, (uint32_t*)nullptr,
+                [&](uint32_t, uint32_t tx, uint32_t ty) {
+                    atomicAdd(&s_cnt[ty * gx + tx], 1u);
+                    return false;
+                },
+                [](uint32_t, uint32_t, uint32_t) {});
+        }
     }
     if (!EMIT) {
         __syncthreads();

@@ -25,6 +25,28 @@ __device__ __forceinline__ float edge_min(float A, float B, float C, float rcpC,
     return 0.5f * (A * dxe * dxe + C * t * t) + B * dxe * t;
 }
 
+// Whole-tile part of quadrant_mask below (same arithmetic, same decision): false exactly when quadrant_mask returns 0
+// through one of its first exits, i.e. when no pixel of the 16x16 tile can receive alpha >= 1/255 from this Gaussian.
+__device__ __forceinline__ bool tile_may_blend(float2 xy, float4 co, float tile_px, float tile_py)
+{
+    const float A = co.x, B = co.y, C = co.z, o = co.w;
+    if (!(o >= (1.0f / 255.0f))) return false;
+    if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return true;
+    const float dxl = xy.x - (tile_px + 15.0f), dxh = xy.x - tile_px;
+    const float dyl = xy.y - (tile_py + 15.0f), dyh = xy.y - tile_py;
+    if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;
+    const float tau = __logf(255.0f * o);
+    const float rcpA = __builtin_amdgcn_rcpf(A), rcpC = __builtin_amdgcn_rcpf(C);
+    const float e0 = edge_min(A, B, C, rcpC, dxl, dyl, dyh);
+    const float e1 = edge_min(A, B, C, rcpC, dxh, dyl, dyh);
+    const float e2 = edge_min(C, B, A, rcpA, dyl, dxl, dxh);
+    const float e3 = edge_min(C, B, A, rcpA, dyh, dxl, dxh);
+    const float qmin = fminf(fminf(e0, e1), fminf(e2, e3));
+    const float mx = fmaxf(fabsf(dxl), fabsf(dxh)), my = fmaxf(fabsf(dyl), fabsf(dyh));
+    const float mag = 0.5f * (A * mx * mx + C * my * my) + fabsf(B) * mx * my;
+    return !(qmin > tau + 1e-5f * mag + 1e-4f);
+}
+
 // Bit q (= qy*2 + qx) set  <=>  the 8x8 pixel quadrant q of the tile at (tile_px, tile_py) may receive
 // alpha >= 1/255 from this Gaussian.  xy: pixel-space mean; co: conic (A,B,C) + opacity.
 __device__ __forceinline__ uint32_t quadrant_mask(float2 xy, float4 co, float tile_px, float tile_py)

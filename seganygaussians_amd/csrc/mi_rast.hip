@@ -281,8 +281,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (prefiltered) HIP_TRY(hipMemsetAsync(cull_counter, 0, sizeof(int), stream));
     const int ntiles = (int)(vp.grid_x * vp.grid_y);
     if (P >= (1 << RANK_BITS)) return fail(MI_RAST_ERR_INVALID, "more than 2^28 Gaussians");
+    if (vp.grid_x > 2047u || vp.grid_y > 2047u) return fail(MI_RAST_ERR_INVALID, "image too large: more than 2047 tiles along one axis");
     if (ntiles > BIN_MAX_TILES)
-        return fail(MI_RAST_ERR_INVALID, "image too large: more than 31680 tiles (e.g. 3840 x 2112 px at 16-px tiles)");
+        return fail(MI_RAST_ERR_INVALID, "image too large: more than 29632 tiles (e.g. 3840 x 1968 px at 16-px tiles)");
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
         HIP_TRY(hipMemsetAsync(img.num_rendered, 0, R_SLOTS * R_SLOT_STRIDE * sizeof(int), stream));
@@ -303,7 +304,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     {
         static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
         if (!attr_set) {
-            const int max_lds = (int)((BIN_MAX_TILES + 9 * 1024 + 16) * sizeof(uint32_t));
+            const int max_lds = (int)((BIN_MAX_TILES + 11 * 1024 + 16) * sizeof(uint32_t));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -377,7 +378,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), bin_lds + 6 * 1024 * sizeof(uint32_t), stream, P, geom.rank_rec,
+            hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P, geom.rank_rec,
                                img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
         }
         STAGE_CHECK("emit ranks");
