@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Randomised parity sweep (GPU): many small random configurations against the oracle -- image sizes that are not
+multiples of 16, all channel counts, SH degrees, cov3D_precomp, mask/depth variant, random backgrounds, scale
+modifiers, dense and sparse scenes, exact depth ties.  usage: fuzz_parity.py [n_cases] [seed]"""
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import saga_oracle as so  # noqa: E402
+from seganygaussians_amd import scenes  # noqa: E402
+from tests import helpers as hp  # noqa: E402
+
+
+def one_case(rng, k):
+    C = int(rng.choice([3, 3, 32, 32, 64]))
+    W, H = int(rng.integers(17, 420)), int(rng.integers(17, 300))
+    P = int(rng.choice([1, 7, 300, 3000, 20000, 60000]))
+    with_shs = bool(C == 3 and rng.random() < 0.5)
+    use_mask = bool(C == 3 and not with_shs and rng.random() < 0.4)
+    kw = dict(seed=int(rng.integers(1 << 30)), focal=float(rng.uniform(0.4, 1.6) * W),
+              log_scale=math.log(float(rng.uniform(0.005, 0.3))), log_scale_std=float(rng.uniform(0.1, 1.0)),
+              with_shs=with_shs, sh_degree=int(rng.integers(0, 4)) if with_shs else 0,
+              use_cov=bool(rng.random() < 0.25), use_mask=use_mask, bg="random" if rng.random() < 0.5 else None,
+              scale_modifier=float(rng.choice([1.0, 1.0, 0.6, 1.7])), camera=str(rng.choice(["front", "orbit"])))
+    inp = hp.make_inputs(P, W, H, C, **kw)
+    if kw["camera"] == "front" and rng.random() < 0.3 and P > 10:   # exact depth ties
+        m = np.ascontiguousarray(inp.means3D, np.float32)
+        m[: P // 2, 2] = np.float32(rng.uniform(2.0, 6.0))
+        inp.means3D = m
+    desc = f"case {k}: C={C} {W}x{H} P={P} " + " ".join(f"{a}={b}" for a, b in kw.items() if a != "seed")
+    one_case.desc = desc
+    gpu = hp.GpuRun(inp).forward()
+    fwd = so.forward(inp)
+    hp.compare_integer_path(gpu, fwd)
+    hp.compare_float_forward(gpu, fwd)
+    dL = scenes.make_grad_image(C, H, W, seed=k)
+    dLm = (rng.normal(0, 1, (1, H, W)) / (W * H)).astype(np.float32) if use_mask else None
+    grads = gpu.backward(dL, dLm)
+    bwd = so.backward(inp, fwd, dL, None if dLm is None else dLm[0])
+    hp.compare_gradients(grads, bwd)
+    return desc, fwd.num_rendered
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for k in range(n):
+        try:
+            desc, R = one_case(rng, k)
+            print("ok  ", desc, "R =", R, flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("FAIL", getattr(one_case, "desc", k), repr(e)[:400], flush=True)
+    print(f"{n - bad} / {n} cases passed")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
