@@ -35,12 +35,12 @@ constexpr int DLROW = 33;  // padded gradient-image staging row (floats; 32 chan
 // padded feature row (floats; conflict-free 16-lane b128 operand reads), waves per SIMD the registers allow.
 template <int C>
 struct BwdCfg {
-    static constexpr int RB2 = C == 32 ? 80 : 128;
+    static constexpr int RB2 = C == 32 ? 80 : 128;  // C == 16 is the RGB kernel (3 real channels padded to one MFMA block)
     static constexpr int FROW = C + 4;
     static constexpr int NBITS = (RB2 + 63) / 64;
     static constexpr int FEAT4 = (RB2 + 1) * FROW / 4;  // + one all-zero row for the list padding
     static constexpr int POOL4 = FEAT4 + 2 * 4 * CHK * WROW / 4;
-    static constexpr int WAVES = C == 32 ? 3 : 2;
+    static constexpr int WAVES = C == 64 ? 2 : 3;
     static_assert(POOL4 * 4 >= 4 * 64 * DLROW, "gradient-image staging must fit in the aliased buffers");
     static_assert(RB2 + FROW / 4 <= 256, "staging roles are assigned by thread index");
 };
@@ -57,11 +57,15 @@ struct BwdPar {
 // for its full 32 cycles (tools/valu_rate_probe.hip, tools/interleave_probe.hip, tools/overlap_probe.hip).  Hence:
 // few instructions per (row, pixel), row parameters fetched by LDS broadcast reads (not VALU), no selects where
 // arithmetic with alpha = 0 does the same, and the register budget of 3 waves per SIMD.
-template <int C>
+// C: channels as the MFMA tiling sees them (16, 32, 64); CR: channels in memory (CR == C, or 3 for RGB padded to C = 16).
+// MASKGRAD (RGB only): the DEPTH variant's dL_dmask (DEPTH/cuda_rasterizer/backward.cu:457,516) rides as channel CR of
+// the dF contraction only -- the mask's image gradient does not enter dL/dalpha -- and lands in field 6 of gpack.
+template <int C, int CR = C, bool MASKGRAD = false>
 __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
     int W, int H, const float* __restrict__ bg_color, const float* __restrict__ colors,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    const float* __restrict__ dL_dout_mask,
     float* __restrict__ gpack /*[P,8] packed field gradients*/, float* __restrict__ dL_dcolors,
     int ablate /* timing experiments only; 0 in production */)
 {
@@ -101,9 +105,15 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     const size_t pix_safe = inside ? pix_id : 0;
     const int last_contributor = inside ? (int)n_contrib[pix_safe] : 0;
     const float T_final = inside ? final_Ts[pix_safe] : 0;
+    static_assert(CR == C || (C == 16 && CR == 3), "padded layout is the RGB case only");
+    static_assert(!MASKGRAD || CR == 3, "the mask gradient belongs to the RGB (DEPTH variant) kernel");
     float dLpix[C];
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) dLpix[ch] = dL_dpixels[(size_t)ch * HW + pix_safe];
+    for (int ch = 0; ch < C; ch++) {
+        if (ch < CR) dLpix[ch] = dL_dpixels[(size_t)ch * HW + pix_safe];
+        else if (MASKGRAD && ch == CR) dLpix[ch] = dL_dout_mask[pix_safe];
+        else dLpix[ch] = 0.f;
+    }
     const BlendRec* rec = blend_rec + range.x;
     BlendRec cur;
     if (tid < RB2 && tid < NS) cur = rec[NS - 1 - tid];
@@ -123,12 +133,13 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     float bg_dot_dpixel = 0.f;  // bg . dL of this lane's own pixel (backward.cu:533-535)
     {
         float* stage = reinterpret_cast<float*>(s_pool) + wave * (64 * DLROW);
+        constexpr int PASS = C < 32 ? C : 32;  // channels per pass through the staging rows
 #pragma unroll
-        for (int h = 0; h < C / 32; h++) {  // 32 channels per pass through the staging rows
+        for (int h = 0; h < C / PASS; h++) {
 #pragma unroll
-            for (int c = 0; c < 32; c++) {
-                const float v = inside ? dLpix[32 * h + c] : 0.f;
-                bg_dot_dpixel += bg_color[32 * h + c] * v;
+            for (int c = 0; c < PASS; c++) {
+                const float v = inside ? dLpix[PASS * h + c] : 0.f;
+                if (PASS * h + c < CR) bg_dot_dpixel += bg_color[PASS * h + c] * v;
                 stage[lane * DLROW + c] = v;
             }
             if (h == 0) {
@@ -137,20 +148,21 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
-            // lanes whose CPL channels lie in this pass (all of them when C == 32)
-            const bool mine = (CPL * kq) / 32 == h;
-            const int c0 = (CPL * kq) % 32;
+            // lanes whose CPL channels lie in this pass (all of them when C <= 32)
+            const bool mine = (CPL * kq) / PASS == h;
+            const int c0 = (CPL * kq) % PASS;
 #pragma unroll
             for (int pb = 0; pb < 4; pb++)
 #pragma unroll
                 for (int s = 0; s < CPL; s++) {
-                    const float v = stage[(16 * pb + n16) * DLROW + (mine ? c0 + s : s)];
-                    if (C == 32 || mine) dLB[pb][s] = v;
+                    float v = stage[(16 * pb + n16) * DLROW + (mine ? c0 + s : s)];
+                    if (MASKGRAD && CPL * kq + s == CR) v = 0.f;  // the mask plane is no part of S
+                    if (C <= 32 || mine) dLB[pb][s] = v;
                 }
 #pragma unroll
             for (int s = 0; s < 16; s++)
 #pragma unroll
-                for (int nb = 0; nb < 2; nb++) dLT[2 * h + nb][s] = stage[(16 * kq + s) * DLROW + 16 * nb + n16];
+                for (int nb = 0; nb < PASS / 16; nb++) dLT[(PASS / 16) * h + nb][s] = stage[(16 * kq + s) * DLROW + 16 * nb + n16];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
     }
@@ -211,8 +223,16 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
         for (int k = 0; k < (RB2 * F4 + BATCH - 1) / BATCH; k++) {
             const int e = tid + BATCH * k;
             const int g = e / F4, part = e % F4;
-            if (g < nr && !(ablate & 4))
-                s_feat4[g * (FROW / 4) + part] = reinterpret_cast<const float4*>(colors + (size_t)__float_as_int(s_par[g].q1.w) * C)[part];
+            if (g < nr && !(ablate & 4)) {
+                const size_t gid = (size_t)__float_as_int(s_par[g].q1.w);
+                if constexpr (CR == C) {
+                    s_feat4[g * (FROW / 4) + part] = reinterpret_cast<const float4*>(colors + gid * C)[part];
+                } else {  // RGB: three floats per Gaussian, the other 13 operand channels are zero
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (part == 0) v = make_float4(colors[gid * 3 + 0], colors[gid * 3 + 1], colors[gid * 3 + 2], 0.f);
+                    s_feat4[g * (FROW / 4) + part] = v;
+                }
+            }
         }
         __syncthreads();
 
@@ -339,7 +359,11 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 const uint32_t gid = (uint32_t)__shfl(my_gid, row, 64);
                 if (act && !(ablate & 64)) {
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++) atomicAdd(&dL_dcolors[(size_t)gid * C + 16 * nb + n16], facc[nb][r]);
+                    for (int nb = 0; nb < NB; nb++) {
+                        const int ch = 16 * nb + n16;
+                        if (ch < CR) atomicAdd(&dL_dcolors[(size_t)gid * CR + ch], facc[nb][r]);
+                        else if (MASKGRAD && ch == CR) atomicAdd(&gpack[(size_t)gid * 8 + 6], facc[nb][r]);
+                    }
                 }
                 if (n16 < 8) my_mom[row * 8 + n16] = macc[r];
             }

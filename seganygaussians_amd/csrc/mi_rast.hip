@@ -652,18 +652,20 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     {
         StageTimer t(stream, MI_STAGE_BLEND_BWD);
         HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float), stream));
-        if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor);
-        else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
-        else if (channels == 32 && !(g_ablate & 1024))
-            hipLaunchKernelGGL(blend_bwd_mfma_kernel<32>, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                               bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib,
-                               dL_dpix, geom.bwd_pack, dL_dcolor, g_ablate);
-        else if (channels == 64 && !(g_ablate & 1024))
-            hipLaunchKernelGGL(blend_bwd_mfma_kernel<64>, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                               bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib,
-                               dL_dpix, geom.bwd_pack, dL_dcolor, g_ablate);
-        else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
-        else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
+#define LAUNCH_BWD_MFMA(...)                                                                                              \
+    hipLaunchKernelGGL((blend_bwd_mfma_kernel<__VA_ARGS__>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,    \
+                       bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib, dL_dpix, \
+                       dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
+        if (g_ablate & 1024) {  // the VALU kernels (timing comparisons)
+            if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor);
+            else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
+            else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
+            else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
+        } else if (maskgrad) LAUNCH_BWD_MFMA(16, 3, true);
+        else if (channels == 3) LAUNCH_BWD_MFMA(16, 3, false);
+        else if (channels == 32) LAUNCH_BWD_MFMA(32);
+        else LAUNCH_BWD_MFMA(64);
+#undef LAUNCH_BWD_MFMA
     }
     if (g_ablate & 32) {
         float dbg[48];
