@@ -10,11 +10,11 @@
 //      16384 of them in use; culled Gaussians go to one extra bucket;
 //   2. count per (workgroup slice, bucket) in LDS, scan over (bucket, slice), scan over buckets (binning.h);
 //   3. scatter (key - min_bits, index) pairs to their bucket with LDS cursors (arrival order arbitrary);
-//   4. one workgroup per bucket sorts its pairs in LDS by (key, index) -- by counting for buckets up to 512 pairs,
-//      else LSD radix over the index digits, then over the s key bits that differ inside a bucket -- and writes sorted_idx[rank] plus the 32-byte rank record
-//      (mean, conic, opacity, radius, id) that the binning passes read coalesced.  Buckets over 1024 pairs go to a
-//      second kernel (up to 8192 in LDS, beyond that ping-ponging in HBM): dense depth layers cost time, not
-//      correctness.
+//   4. the pairs of a bucket are ordered by (key, index) and sorted_idx[rank] plus the 32-byte rank record (mean,
+//      conic, opacity, radius, id: what the binning passes read coalesced) are written: buckets of up to 256 pairs by
+//      one wave each (ranking by counting, no barriers); longer ones -- listed by the range scan -- by a workgroup each
+//      (counting up to 512 pairs, LSD radix over the index digits and the s key bits that differ inside a bucket up to
+//      2048 pairs in LDS, ping-ponging in HBM beyond): dense depth layers cost time, not correctness.
 #pragma once
 
 #include "binning.h"
@@ -24,9 +24,9 @@ namespace mirast {
 constexpr int DS_NB = 16384;
 constexpr int DS_NBK = DS_NB + 1;  // + the bucket of culled Gaussians
 constexpr int DS_MAX_WG = 128;
-constexpr int DS_SMALL = 1024;   // pairs per bucket sorted by the one-workgroup-per-bucket kernel
+constexpr int DS_WAVE = 256;     // pairs per bucket ranked by ONE wave (four buckets per workgroup, no barriers)
 constexpr int DS_COUNTING = 512;  // buckets up to this size are ranked by counting instead of radix passes
-constexpr int DS_LARGE = 8192;   // pairs per bucket the second kernel holds in LDS
+constexpr int DS_LARGE = 2048;   // pairs per bucket the second kernel holds in LDS (36 KB: four workgroups per CU)
 
 // Key range of the view -> {min key, bucket shift}.  Call from every thread (reads 2 x R_SLOTS words, L2-resident).
 struct DepthMap {
@@ -190,9 +190,58 @@ __device__ __forceinline__ void radix_pass_pairs(Src src, Dst dst, int n, int sh
     __syncthreads();
 }
 
+// Buckets of up to DS_WAVE pairs (the common case: ~100 pairs on a 1 M-Gaussian view): one WAVE per bucket ranks its
+// pairs by counting -- every pair is compared with every other one through LDS broadcast reads; (key, index) pairs
+// are distinct, so the ranks are a permutation -- and scatters sorted_idx / the 32-byte records by rank.
+__global__ void __launch_bounds__(256) depth_bucket_sort_wave_kernel(const uint2* __restrict__ ranges,
+                                                                     const uint2* __restrict__ pairs,
+                                                                     const BlendRec* __restrict__ index_rec,
+                                                                     uint32_t* __restrict__ sorted_idx,
+                                                                     BlendRec* __restrict__ rank_rec)
+{
+    __shared__ uint32_t s_k[4][DS_WAVE];
+    __shared__ uint32_t s_v[4][DS_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= DS_NB) return;
+    const uint2 range = ranges[b];
+    const int n = (int)(range.y - range.x);
+    if (n == 0 || n > DS_WAVE) return;  // longer buckets are on the big-bucket list
+    constexpr int EPL = DS_WAVE / 64;   // elements per lane
+    uint64_t mine[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; t++) {
+        const int e = lane + 64 * t;
+        uint2 p = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (e < n) {
+            p = pairs[range.x + e];
+            s_k[wave][e] = p.x;
+            s_v[wave][e] = p.y;
+        }
+        mine[t] = ((uint64_t)p.x << 32) | p.y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    int rank[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; t++) rank[t] = 0;
+    for (int q = 0; q < n; q++) {
+        const uint64_t other = ((uint64_t)s_k[wave][q] << 32) | s_v[wave][q];
+#pragma unroll
+        for (int t = 0; t < EPL; t++) rank[t] += other < mine[t] ? 1 : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < EPL; t++) {
+        if (lane + 64 * t < n) {
+            const uint32_t g = (uint32_t)mine[t];
+            rank_rec[range.x + rank[t]] = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
+            sorted_idx[range.x + rank[t]] = g;
+        }
+    }
+}
+
 // Sorts the pairs of one bucket by (key, index) and writes sorted_idx / rank_rec for its ranks.
-// BIG = false: one workgroup per bucket, buckets of 1..CAP pairs.  BIG = true: workgroups walk the list of buckets
-// with more than LO pairs (built by tile_ranges_kernel); up to CAP pairs in LDS, more than that in HBM.
+// BIG = true (the only instantiation in use): workgroups walk the list of buckets with more than LO pairs (built by
+// tile_ranges_kernel); up to CAP pairs in LDS (counting up to 512, LSD radix above), more than that in HBM.
 template <int LO, int CAP, bool BIG>
 __global__ void __launch_bounds__(256) depth_bucket_sort_kernel(const uint2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ big_list,

@@ -334,13 +334,12 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                            (const int*)img.num_rendered);
         hipLaunchKernelGGL(scan_partials_kernel, dim3((DS_NBK + 63) / 64), dim3(1024), 0, stream, DS_NBK, nwg_d, ds.partial, ds.total);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), (DS_NBK + 1) * sizeof(uint32_t), stream, DS_NBK, ds.total, ds.ranges, ds.out2,
-                           (uint32_t)DS_SMALL, DS_NB, ds.big_list);
+                           (uint32_t)DS_WAVE, DS_NB, ds.big_list);
         hipLaunchKernelGGL(depth_bucket_kernel<true>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
                            geom.depth_key, ds.partial, ds.ranges, ds.pairs, geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
-        hipLaunchKernelGGL((depth_bucket_sort_kernel<0, DS_SMALL, false>), dim3(DS_NB), dim3(256), 0, stream, ds.ranges,
-                           (const uint32_t*)nullptr, ds.pairs, ds.pairs_tmp, idx_passes, geom.index_rec,
-                           geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
-        hipLaunchKernelGGL((depth_bucket_sort_kernel<DS_SMALL, DS_LARGE, true>), dim3(256), dim3(256), 0, stream, ds.ranges,
+        hipLaunchKernelGGL(depth_bucket_sort_wave_kernel, dim3((DS_NB + 3) / 4), dim3(256), 0, stream, ds.ranges, ds.pairs,
+                           geom.index_rec, geom.sorted_idx, geom.rank_rec);
+        hipLaunchKernelGGL((depth_bucket_sort_kernel<DS_WAVE, DS_LARGE, true>), dim3(2048), dim3(256), 0, stream, ds.ranges,
                            ds.big_list, ds.pairs, ds.pairs_tmp, idx_passes, geom.index_rec,
                            geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
     }

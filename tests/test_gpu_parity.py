@@ -207,12 +207,13 @@ def _max_tile_list(gpu):
 
 def test_depth_ties_dense_layers():
     """Thousands of Gaussians at EXACTLY the same depth (front camera: view z == world z): the (depth, index) order
-    must come out of the bucketed depth ordering bit-exactly -- one bucket of 6000 pairs (LDS radix path), then a
-    bucket of 12000 (> 8192: HBM ping-pong path) next to a 1-ulp neighbour layer and a far layer."""
-    inp = hp.make_inputs(6000, 256, 160, 3, seed=11, log_scale=math.log(0.01), log_scale_std=0.3)
-    inp.means3D = np.ascontiguousarray(inp.means3D, np.float32)
-    inp.means3D[:, 2] = 4.0
-    _fwd_bwd(inp)
+    must come out of the bucketed depth ordering bit-exactly -- one bucket of 1500 pairs (LDS radix path), then
+    buckets of 6000 and 12000 (> 2048: HBM ping-pong path) next to a 1-ulp neighbour layer and a far layer."""
+    for n in (1500, 6000):
+        inp = hp.make_inputs(n, 256, 160, 3, seed=11, log_scale=math.log(0.01), log_scale_std=0.3)
+        inp.means3D = np.ascontiguousarray(inp.means3D, np.float32)
+        inp.means3D[:, 2] = 4.0
+        _fwd_bwd(inp)
     inp = hp.make_inputs(20000, 256, 160, 3, seed=12, log_scale=math.log(0.008), log_scale_std=0.3)
     m = np.ascontiguousarray(inp.means3D, np.float32)
     m[:12000, 2] = 3.0
