@@ -30,7 +30,7 @@ STAGE_OF = {"blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_mfma_kernel": "bl
             "preprocess_fwd_kernel": "preprocess", "bin_ranks_kernel<true>": "emit", "tile_sort_kernel": "tile_sort",
             "bin_ranks_kernel<false>": "tile_scan", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
             "depth_bucket_kernel<false>": "depth_sort", "depth_bucket_kernel<true>": "depth_sort",
-            "depth_bucket_sort_kernel": "depth_sort", "geometry_bwd_kernel": "geom_bwd"}
+            "depth_bucket_sort_kernel": "depth_sort", "depth_bucket_sort_wave_kernel": "depth_sort", "geometry_bwd_kernel": "geom_bwd"}
 
 rows = list(csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))))
 agg = {}
