@@ -159,10 +159,13 @@ def main():
         # counters: one extra (un-timed) native forward whose opaque buffers we can inspect
         from seganygaussians_amd.rasterizer import rasterize_gaussians_native
         e = torch.empty(0)
+        # E and L are counters of the REFERENCE algorithm (positions in its full tile lists): full-list mode for this call
+        prev_mode = _lib.load().mi_rast_set_full_lists(1)
         with torch.no_grad():
             num_rendered, _c, _r, _g, _b, imgbuf = rasterize_gaussians_native(
                 C, False, settings.bg, means3D, feats, opac, None, scales, rots, 1.0, e, settings.viewmatrix,
                 settings.projmatrix, cam.tanfovx, cam.tanfovy, H, W, e, 0, settings.campos, False, False)
+        _lib.load().mi_rast_set_full_lists(prev_mode)
         _, ioff = _lib.image_layout(W, H)
         tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
         nc = imgbuf[ioff["n_contrib"]:ioff["n_contrib"] + 4 * W * H].view(torch.int32).reshape(H, W)

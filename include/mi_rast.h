@@ -148,6 +148,14 @@ const char* mi_rast_version(void);
 int mi_rast_supported_channels(int* out, int n);
 /* Reference helper getHigherMsb (CF/cuda_rasterizer/rasterizer_impl.cu:35-50), host side. */
 uint32_t mi_rast_get_higher_msb(uint32_t n);
+/* List mode of the forward passes (process-wide; returns the previous value).
+ * 0 (default): "lean" -- only the (Gaussian, tile) overlaps that pass the exact-conservative cull are listed and
+ *    sorted; blend-list positions (and n_contrib, tile_consumed) count blend-list records.  Every output of the
+ *    reference API (images, radii, gradients, num_rendered) is identical to the full mode's.
+ * 1: "full" -- additionally materialises the reference's point_list (CF/cuda_rasterizer/rasterizer_impl.cu:300-317)
+ *    and full-list positions, so that the integer path can be compared bit-exactly with the oracle.  The reference's
+ *    `debug` flag implies it for that call. */
+int mi_rast_set_full_lists(int on);
 
 /* Private-layout maps of the three opaque buffers, so tests can compare the integer path
  * bit-exactly with the oracle.  Each call fills `offsets` (bytes from the buffer start) for the

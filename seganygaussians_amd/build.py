@@ -18,7 +18,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "mi_rast.h")
 # -ffp-contract=off is part of the numeric contract: the geometry path that feeds the
 # integer tile/sort results must round every binary32 op separately, like the oracle.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
-               "-fPIC", "-shared", "-Wno-unused-result"]
+               "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize"]
 
 
 def find_hipcc() -> str:

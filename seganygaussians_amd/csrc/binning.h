@@ -248,7 +248,11 @@ inline int bin_workgroups(int P)
     return blocks < 1 ? 1 : (blocks > BIN_MAX_WG ? BIN_MAX_WG : blocks);
 }
 
-template <bool EMIT>
+// FULL (emit pass): every overlap is stored, culled ones with mask 0 -- the per-tile sort then reproduces the reference's
+// point_list.  !FULL ("lean", the default of the product path): `entries` was zero-filled and only the overlaps that
+// pass the cull are stored (a third of them; non-zero because their mask is), at the front of the slice's share of
+// the tile's segment; the per-tile sort drops the zeros and never materialises point_list.
+template <bool EMIT, bool FULL = true>
 __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
                                                                 uint32_t* __restrict__ partial,
                                                                 const uint2* __restrict__ ranges,
@@ -298,12 +302,15 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
                 rw, tid, rmin, rmax, count, s_queue + wave * 128,
                 [&](uint32_t owner, uint32_t tx, uint32_t ty) {
                     if (tile_may_blend(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y))) return true;
-                    const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
-                    entries[slot] = rank_of(owner);
+                    if (FULL) {
+                        const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
+                        entries[slot] = rank_of(owner);
+                    }
                     return false;
                 },
                 [&](uint32_t owner, uint32_t tx, uint32_t ty) {
                     const uint32_t qmask = quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
+                    if (!FULL && qmask == 0u) return;
                     const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
                     entries[slot] = rank_of(owner) | (qmask << RANK_BITS);
                 });
@@ -492,7 +499,60 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, SparePtr 
     if (tid == 0) blend_count[tile] = ns;
 }
 
-template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT>
+// Lean lists: the non-zero entries of a zero-filled segment, compacted into dst (order irrelevant: they are sorted
+// next); returns their number.  Every wave owns a contiguous share; one barrier exchanges the counts.
+template <int NW, typename SrcPtr, typename DstPtr>
+__device__ __forceinline__ int compact_nonzero(SrcPtr src, DstPtr dst, int n, int tid, uint32_t* s_wcount)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int chunks = (n + 63) >> 6;
+    const int cpw = (chunks + NW - 1) / NW;
+    const int begin = min(n, wave * cpw * 64), end = min(n, (wave + 1) * cpw * 64);
+    uint32_t mine = 0;
+    for (int i0 = begin; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t v = i < end ? (uint32_t)src[i] : 0u;
+        mine += (uint32_t)__builtin_popcountll(ballot64(v != 0u));
+    }
+    if (lane == 0) s_wcount[wave] = mine;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t c = s_wcount[w];
+        base += w < wave ? c : 0u;
+        total += c;
+    }
+    for (int i0 = begin; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t v = i < end ? (uint32_t)src[i] : 0u;
+        const uint64_t bal = ballot64(v != 0u);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (v != 0u) dst[base + below] = v;
+        base += (uint32_t)__builtin_popcountll(bal);
+    }
+    __syncthreads();
+    return (int)total;
+}
+
+// Lean lists: every sorted entry is a survivor; its position in the blend list stands in for the position in the
+// reference's full list (the blend kernels only compare positions of one list with each other).
+template <int NW, typename SrcPtr>
+__device__ __forceinline__ void emit_blend_list(SrcPtr sorted_entries, int m, uint2 range, int tid,
+                                                const BlendRec* __restrict__ rank_rec, BlendRec* __restrict__ blend_rec,
+                                                uint32_t* __restrict__ blend_count, uint32_t tile)
+{
+    BlendRec* rec = blend_rec + range.x;
+    for (int j = tid; j < m; j += NW * 64) {
+        const uint32_t e = sorted_entries[j];
+        BlendRec r = rank_rec[e & RANK_MASK];
+        r.pm = ((uint32_t)j << 4) | (e >> RANK_BITS);
+        rec[j] = r;
+    }
+    if (tid == 0) blend_count[tile] = (uint32_t)m;
+}
+
+template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT, bool FULL = true>
 __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ entries,
                                                         uint32_t* __restrict__ scratch,
                                                         const uint32_t* __restrict__ sorted_idx,
@@ -514,27 +574,42 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__
     if (n > CAP && !GLOBAL_FALLBACK) return;
     uint32_t* seg = entries + range.x;
     if (n <= CAP) {
-        for (int i = tid; i < n; i += NT) s_a[i] = seg[i];
-        __syncthreads();
+        int m = n;
+        if (FULL) {
+            for (int i = tid; i < n; i += NT) s_a[i] = seg[i];
+            __syncthreads();
+        } else {
+            for (int i = tid; i < n; i += NT) s_b[i] = seg[i];
+            __syncthreads();
+            m = compact_nonzero<NW>(s_b, s_a, n, tid, s_wcount);
+        }
         uint32_t* a = s_a;
         uint32_t* b = s_b;
         for (int p = 0; p < passes; p++) {
-            radix_pass<NW>(a, b, n, 8 * p, s_hist, tid);
+            radix_pass<NW>(a, b, m, 8 * p, s_hist, tid);
             uint32_t* t = a;
             a = b;
             b = t;
         }
-        emit_tile_lists<NW>(a, b, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
+        if (FULL) emit_tile_lists<NW>(a, b, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
+        else emit_blend_list<NW>(a, m, range, tid, rank_rec, blend_rec, blend_count, blockIdx.x);
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
+        int m = n;
+        if (!FULL) {
+            m = compact_nonzero<NW>(seg, b, n, tid, s_wcount);
+            a = b;
+            b = seg;
+        }
         for (int p = 0; p < passes; p++) {
-            radix_pass<NW>(a, b, n, 8 * p, s_hist, tid);
+            radix_pass<NW>(a, b, m, 8 * p, s_hist, tid);
             uint32_t* t = a;
             a = b;
             b = t;
         }
-        emit_tile_lists<NW>(a, b, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
+        if (FULL) emit_tile_lists<NW>(a, b, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, blockIdx.x, s_wcount);
+        else emit_blend_list<NW>(a, m, range, tid, rank_rec, blend_rec, blend_count, blockIdx.x);
     }
 }
 

@@ -47,7 +47,9 @@ struct BwdCfg {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// One staged record: {x, y, conic a, conic b} {conic c, opacity, list position (int bits), Gaussian id (int bits)}
+// One staged record: {x, y, -a/2, -b} {-c/2, opacity, list position (int bits), Gaussian id (int bits)} with the conic
+// (a, b, c) pre-scaled so that power = ((-a/2 dx) dx + (-c/2 dy) dy) + (-b dx) dy -- bit-identical to the reference
+// expression -0.5f (a dx dx + c dy dy) - b dx dy (scaling by -1/2 and -1 commutes with every rounding), two VALU fewer.
 struct BwdPar {
     float4 q0, q1;
 };
@@ -77,9 +79,10 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     __shared__ BwdPar s_par[RB2 + 1];                // [RB2] = padding record (never valid)
     __shared__ float4 s_pool[POOL4];                 // feature rows | w rows | u rows  (prologue: gradient-image staging)
     __shared__ uint64_t s_bits[4][NBITS];
-    __shared__ uint16_t s_list[4][RB2 + CHK];        // per quadrant: BYTE OFFSETS of its records in s_par, back to front
+    __shared__ uint32_t s_list[4][RB2 + CHK];        // per quadrant: BYTE OFFSETS of its records in s_par, back to front
     __shared__ float4 s_mom4[4][CHK * 8 / 4];
     __shared__ int s_Lt[4];
+    __shared__ uint32_t s_dump[64];                  // landing zone of the feature-row prefetch (never read)
     float4* const s_feat4 = s_pool;
 
     const int tid = threadIdx.x;
@@ -117,6 +120,11 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     const BlendRec* rec = blend_rec + range.x;
     BlendRec cur;
     if (tid < RB2 && tid < NS) cur = rec[NS - 1 - tid];
+    // Gaussian id of this thread's record in the batch AFTER the one `cur` belongs to: its feature row is pulled into
+    // L2 one batch ahead (an LDS-DMA load of one dword per 128-byte line into a dump area costs no registers), so the
+    // gather of stage B -- a dependent global access -- finds its lines on the chip.
+    uint32_t next_id = 0;
+    if (tid < RB2 && RB2 + tid < NS) next_id = rec[NS - 1 - (RB2 + tid)].id;
     int wave_Lt = last_contributor;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wave_Lt = max(wave_Lt, __shfl_xor(wave_Lt, o, 64));
@@ -198,12 +206,12 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
         __syncthreads();                   // LDS reuse (first batch: the gradient-image staging reads are done)
         // ---- A: records -> LDS; next batch's record -> registers; quadrant bitmaps
         if (tid < nr) {
-            s_par[tid].q0 = make_float4(cur.xy.x, cur.xy.y, cur.co.x, cur.co.y);
-            s_par[tid].q1 = make_float4(cur.co.z, cur.co.w, __int_as_float((int)(cur.pm >> 4)), __int_as_float((int)cur.id));
+            s_par[tid].q0 = make_float4(cur.xy.x, cur.xy.y, -0.5f * cur.co.x, -cur.co.y);
+            s_par[tid].q1 = make_float4(-0.5f * cur.co.z, cur.co.w, __int_as_float((int)(cur.pm >> 4)), __int_as_float((int)cur.id));
         }
         if (tid == RB2) {  // padding record: never valid ...
-            s_par[RB2].q0 = make_float4(0.f, 0.f, 1.f, 0.f);
-            s_par[RB2].q1 = make_float4(1.f, 0.f, __int_as_float(0x7fffffff), __int_as_float(0));
+            s_par[RB2].q0 = make_float4(0.f, 0.f, -0.5f, 0.f);
+            s_par[RB2].q1 = make_float4(-0.5f, 0.f, __int_as_float(0x7fffffff), __int_as_float(0));
         }
         if (tid >= 256 - FROW / 4)  // ... and its all-zero feature row (S = 0)
             s_feat4[RB2 * (FROW / 4) + (tid - (256 - FROW / 4))] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -215,7 +223,6 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 if (lane == 0) s_bits[q][wave] = b;
             }
         }
-        if (tid < RB2 && b0 + RB2 + tid < NS) cur = rec[NS - 1 - (b0 + RB2 + tid)];
         TK(2);
         __syncthreads();
         // ---- B: feature rows (padded to FROW floats), gathered by the ids just staged
@@ -234,6 +241,17 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 }
             }
         }
+        // The next batch's records (and the prefetch of their feature rows) are requested only now: vmcnt retires in
+        // order, so a request issued before the gather would make the gather wait for it as well.
+        if (tid < RB2 && b0 + RB2 + tid < NS) {
+            cur = rec[NS - 1 - (b0 + RB2 + tid)];
+            const char* row = reinterpret_cast<const char*>(colors + (size_t)next_id * CR);
+#pragma unroll
+            for (int o = 0; o < CR * 4; o += 128)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + o),
+                                                 (__attribute__((address_space(3))) void*)s_dump, 4, 0, 0);
+        }
+        if (tid < RB2 && b0 + 2 * RB2 + tid < NS) next_id = rec[NS - 1 - (b0 + 2 * RB2 + tid)].id;
         __syncthreads();
 
         // ---- this quadrant's rows, back to front, restricted to positions below the quadrant's max n_contrib;
@@ -245,11 +263,11 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
             const bool cand = ((s_bits[wave][h] >> lane) & 1ull) && ridx < nr && __float_as_int(s_par[ridx < nr ? ridx : 0].q1.z) < wave_Lt;
             const uint64_t b = ballot64(cand);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-            if (cand) s_list[wave][cnt + below] = (uint16_t)(ridx * sizeof(BwdPar));
+            if (cand) s_list[wave][cnt + below] = (uint32_t)(ridx * sizeof(BwdPar));
             cnt += __builtin_popcountll(b);
         }
         cnt = __builtin_amdgcn_readfirstlane(cnt);
-        if (lane < CHK) s_list[wave][cnt + lane] = (uint16_t)(RB2 * sizeof(BwdPar));
+        if (lane < CHK) s_list[wave][cnt + lane] = (uint32_t)(RB2 * sizeof(BwdPar));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (ablate & 1) cnt = 0;
         TK(3);
@@ -301,20 +319,22 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 const float4 p0 = *reinterpret_cast<const float4*>(par_bytes + off);
                 const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + off + 16);
                 const float dx = p0.x - pixfx, dy = p0.y - pixfy;
-                const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
+                const float power = (p0.z * dx * dx + p1.x * dy * dy) + p0.w * dx * dy;
                 const float G = __expf(power);
-                const float a_raw = fminf(0.99f, p1.y * G);
-                const bool valid = (__float_as_int(p1.z) < last_contributor) && power <= 0.0f && a_raw >= (1.0f / 255.0f);
-                const float alpha = valid ? a_raw : 0.f;
-                const float Ge = valid ? G : 0.f;
+                // opacity * G where the row can blend into this pixel at all, else 0; the 1/255 cut is the last test so
+                // that its compare doubles as the ballot (min(0.99, t) >= 1/255  <=>  t >= 1/255)
+                const float t0 = ((__float_as_int(p1.z) < last_contributor) && power <= 0.0f) ? p1.y * G : 0.f;
+                const bool valid = t0 >= (1.0f / 255.0f);
+                const float tG = valid ? t0 : 0.f;   // opacity * G of a contributing row
+                const float alpha = fminf(0.99f, tG);
                 const float om = 1.f - alpha;
                 const float inv = __builtin_amdgcn_rcpf(om);
                 T = T * inv;
                 const float w = alpha * T;  // dchannel_dcolor
-                const float S = Srow[rr];
-                const float dL_dalpha = fmaf(nTb, inv, (S - Rcur) * T);
-                Rcur = fmaf(alpha, S, om * Rcur);
-                const float u = (p1.y * dL_dalpha) * Ge;  // dL/dG * G
+                const float dS = Srow[rr] - Rcur;
+                const float dL_dalpha = fmaf(nTb, inv, dS * T);
+                Rcur = fmaf(alpha, dS, Rcur);  // = alpha S + (1 - alpha) Rcur
+                const float u = tG * dL_dalpha;  // dL/dG * G  (dL/dG = opacity * dL/dalpha, clamp ignored as in the reference)
                 rowmask |= (ballot64(valid) != 0 ? 1u : 0u) << rr;
                 my_wa[rr * WROW + lane] = w;
                 my_ua[rr * WROW + lane] = u;
@@ -377,7 +397,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                     const float4 m0 = reinterpret_cast<const float4*>(my_mom + row * 8)[0];
                     const float4 m1 = reinterpret_cast<const float4*>(my_mom + row * 8)[1];
                     const float M0 = m0.x, M1 = m0.y, M2 = m0.z, M3 = m0.w, M4 = m1.x, M5 = m1.y;
-                    const float ca = mine.q0.z, cb = mine.q0.w, cc = mine.q1.x, op = mine.q1.y;
+                    const float ca = -2.f * mine.q0.z, cb = -mine.q0.w, cc = -2.f * mine.q1.x, op = mine.q1.y;
                     const float gx = mine.q0.x - cxq, gy = mine.q0.y - cyq;
                     // dx = gx - x', dy = gy - y'
                     const float Sdx = gx * M0 - M1;

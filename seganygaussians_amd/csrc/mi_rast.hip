@@ -254,6 +254,7 @@ BinPtrs bin_from(char* base, int R)
 
 // Timing experiments only: MI_RAST_ABLATE=<bitmask> disables pieces of the backward blend (results become wrong).
 int g_ablate = 0;
+int g_full_lists = 0;  // mi_rast_set_full_lists
 int g_ablate_fwd = 0;
 
 bool channels_supported(int c) { return c == 3 || c == 32 || c == 64; }
@@ -307,6 +308,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             const int max_lds = (int)((BIN_MAX_TILES + 11 * 1024 + 16) * sizeof(uint32_t));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -374,11 +376,20 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     char* bin_base = binning_buffer(bin_size, binning_user);
     if (!bin_base) return fail(MI_RAST_ERR_ALLOC, "binning buffer callback returned NULL");
     bin = bin_from(bin_base, R);
+    // Full lists (the reference's point_list and full-list positions) are materialised on request -- the reference's
+    // `debug` flag or mi_rast_set_full_lists(1) -- ; otherwise only the overlaps that pass the cull are listed.
+    const bool full = debug != 0 || g_full_lists != 0;
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P, geom.rank_rec,
-                               img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
+            if (full) {
+                hipLaunchKernelGGL((bin_ranks_kernel<true, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P,
+                                   geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
+            } else {
+                HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint32_t), stream));
+                hipLaunchKernelGGL((bin_ranks_kernel<true, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P,
+                                   geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
+            }
         }
         STAGE_CHECK("emit ranks");
         int rank_bits = 1;
@@ -390,21 +401,25 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             // three list-length classes (256 threads + 20 KB of LDS, 1024 threads + 64 KB, 1024 threads + 112 KB); a class is launched only if
             // some tile needs it.  The longest list was copied to the host right after the range scan, which
             // finished before the emit pass above even started: this wait does not stall the queue.
-            hipLaunchKernelGGL((tile_sort_kernel<0, 2048, false, 256>), dim3(ntiles), dim3(256), 0, stream, img.ranges,
-                               bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
-                               bin.blend_rec, img.blend_count);
+#define LAUNCH_TILE_SORT(LO, CAP, FB, NT)                                                                                 \
+    do {                                                                                                                  \
+        if (full)                                                                                                         \
+            hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT, true>), dim3(ntiles), dim3(NT), 0, stream, img.ranges,  \
+                               bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,          \
+                               bin.blend_rec, img.blend_count);                                                           \
+        else                                                                                                              \
+            hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT, false>), dim3(ntiles), dim3(NT), 0, stream, img.ranges, \
+                               bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,          \
+                               bin.blend_rec, img.blend_count);                                                           \
+    } while (0)
+            LAUNCH_TILE_SORT(0, 2048, false, 256);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
             if (g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
-            if (max_tile_count > 2048)
-                hipLaunchKernelGGL((tile_sort_kernel<2048, 6144, false, 1024>), dim3(ntiles), dim3(1024), 0, stream, img.ranges,
-                                   bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
-                                   bin.blend_rec, img.blend_count);
-            if (max_tile_count > 6144)
-                hipLaunchKernelGGL((tile_sort_kernel<6144, 12288, true, 1024>), dim3(ntiles), dim3(1024), 0, stream, img.ranges,
-                                   bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,
-                                   bin.blend_rec, img.blend_count);
+            if (max_tile_count > 2048) LAUNCH_TILE_SORT(2048, 6144, false, 1024);
+            if (max_tile_count > 6144) LAUNCH_TILE_SORT(6144, 12288, true, 1024);
+#undef LAUNCH_TILE_SORT
         }
         STAGE_CHECK("tile sort");
     }
@@ -490,6 +505,13 @@ int mi_knn_smooth_backward(int P, int C, int K, const int* knn_idx, const int* i
 }
 
 // CF/cuda_rasterizer/rasterizer_impl.cu:35-50
+int mi_rast_set_full_lists(int on)
+{
+    const int prev = g_full_lists;
+    g_full_lists = on ? 1 : 0;
+    return prev;
+}
+
 uint32_t mi_rast_get_higher_msb(uint32_t n)
 {
     uint32_t msb = sizeof(n) * 4;

@@ -86,12 +86,20 @@ class GpuRun:
         self.mask = t(inp.mask)
         self.with_mask = inp.mask is not None
 
-    def forward(self, debug=False):
+    def forward(self, debug=False, full_lists=True):
+        """full_lists=True materialises the reference's point_list / full-list positions (what the bit-exact
+        comparisons with the oracle read); False is the product default ("lean" lists, include/mi_rast.h)."""
+        from seganygaussians_amd import _lib
         i = self.inp
-        res = self.R.rasterize_gaussians_native(
-            i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
-            self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,
-            i.image_width, self.shs, i.sh_degree, self.campos, i.prefiltered, debug)
+        prev = _lib.load().mi_rast_set_full_lists(1 if full_lists else 0)
+        try:
+            res = self.R.rasterize_gaussians_native(
+                i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
+                self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,
+                i.image_width, self.shs, i.sh_degree, self.campos, i.prefiltered, debug)
+        finally:
+            _lib.load().mi_rast_set_full_lists(prev)
+        self.full_lists = bool(full_lists or debug)
         if self.with_mask:
             (self.num_rendered, self.color, self.out_mask, self.out_depth, self.radii, self.geom, self.binning,
              self.img) = res
@@ -144,6 +152,24 @@ class GpuRun:
         R = self.num_rendered
         _, off = _lib.binning_layout(R)
         return dict(point_list=self._view(self.binning, off["point_list"], R, np.uint32))
+
+    def blend_lists(self):
+        """The per-tile blend lists (what the blend kernels walk): concatenated Gaussian ids and quadrant masks in list
+        order, plus the per-tile counts.  Positions (pm >> 4) depend on the list mode and are not returned."""
+        from seganygaussians_amd import _lib
+        R = self.num_rendered
+        i = self.inp
+        W, H = i.image_width, i.image_height
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        _, ioff = _lib.image_layout(W, H)
+        counts = self._view(self.img, ioff["blend_count"], tiles, np.uint32).astype(np.int64)
+        if R == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), counts
+        _, off = _lib.binning_layout(R)
+        rec = self._view(self.binning, off["blend_rec"], 8 * R, np.uint32).reshape(R, 8)
+        ranges = self.img_fields()["ranges"].reshape(-1, 2).astype(np.int64)
+        sel = np.concatenate([np.arange(a, a + c) for (a, _), c in zip(ranges, counts) if c]) if counts.sum() else np.zeros(0, np.int64)
+        return rec[sel, 2].copy(), (rec[sel, 3] & 15).copy(), counts
 
     def sorted_keys(self):
         """The reference's sorted 64-bit key list (tile << 32 | depth bits), which our pipeline never
@@ -211,6 +237,32 @@ def compare_integer_path(gpu: GpuRun, fwd: so.ForwardOut):
     np.testing.assert_array_equal(im["ranges"], st.field(so.F_RANGES), err_msg="tile ranges")
     if gpu.num_rendered:
         np.testing.assert_array_equal(gpu.sorted_keys(), st.field(so.F_KEYS_SORTED), err_msg="sorted (tile|depth) keys")
+
+
+def compare_lean_with_full(inp, full: GpuRun, dL=None, dLm=None, full_grads=None):
+    """The product default ("lean" lists) against the full-list run of the same input: identical blend lists
+    (ids, quadrant masks, order), bit-identical images / final_T / radii; gradients equal up to the order of the
+    atomic float sums."""
+    lean = GpuRun(inp).forward(full_lists=False)
+    assert lean.num_rendered == full.num_rendered
+    np.testing.assert_array_equal(lean.radii.cpu().numpy(), full.radii.cpu().numpy(), err_msg="radii (lean)")
+    ids_l, qm_l, cnt_l = lean.blend_lists()
+    ids_f, qm_f, cnt_f = full.blend_lists()
+    np.testing.assert_array_equal(cnt_l, cnt_f, err_msg="blend list lengths (lean vs full)")
+    np.testing.assert_array_equal(ids_l, ids_f, err_msg="blend list ids (lean vs full)")
+    np.testing.assert_array_equal(qm_l, qm_f, err_msg="blend list quadrant masks (lean vs full)")
+    np.testing.assert_array_equal(lean.color.cpu().numpy().view(np.uint32), full.color.cpu().numpy().view(np.uint32),
+                                  err_msg="out_color bits (lean vs full)")
+    np.testing.assert_array_equal(lean.img_fields()["final_T"].view(np.uint32), full.img_fields()["final_T"].view(np.uint32),
+                                  err_msg="final_T bits (lean vs full)")
+    if full.with_mask:
+        np.testing.assert_array_equal(lean.out_mask.cpu().numpy(), full.out_mask.cpu().numpy(), err_msg="out_mask (lean)")
+        np.testing.assert_array_equal(lean.out_depth.cpu().numpy(), full.out_depth.cpu().numpy(), err_msg="out_depth (lean)")
+    if dL is not None:
+        g = lean.backward(dL, dLm)
+        for k, want in full_grads.items():
+            assert_close(k + " (lean vs full)", g[k], want, rtol=1e-4)  # same sums, different atomic order
+    return lean
 
 
 def compare_float_forward(gpu: GpuRun, fwd: so.ForwardOut, flip_frac=FLIP_FRAC):

@@ -30,6 +30,8 @@ def _fwd_bwd(inp, grad_seed=1, check_int=True, use_mask_grad=False, skip=()):
     grads = gpu.backward(dL, dLm)
     bwd = so.backward(inp, fwd, dL, None if dLm is None else dLm[0])
     rep.update(hp.compare_gradients(grads, bwd, skip=skip))
+    # the product default lists only the overlaps that pass the cull: same blend lists, same results
+    hp.compare_lean_with_full(inp, gpu, dL, dLm, grads)
     return rep, gpu, fwd
 
 
