@@ -82,7 +82,6 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     __shared__ uint32_t s_list[4][RB2 + CHK];        // per quadrant: BYTE OFFSETS of its records in s_par, back to front
     __shared__ float4 s_mom4[4][CHK * 8 / 4];
     __shared__ int s_Lt[4];
-    __shared__ uint32_t s_dump[64];                  // landing zone of the feature-row prefetch (never read)
     float4* const s_feat4 = s_pool;
 
     const int tid = threadIdx.x;
@@ -120,11 +119,6 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     const BlendRec* rec = blend_rec + range.x;
     BlendRec cur;
     if (tid < RB2 && tid < NS) cur = rec[NS - 1 - tid];
-    // Gaussian id of this thread's record in the batch AFTER the one `cur` belongs to: its feature row is pulled into
-    // L2 one batch ahead (an LDS-DMA load of one dword per 128-byte line into a dump area costs no registers), so the
-    // gather of stage B -- a dependent global access -- finds its lines on the chip.
-    uint32_t next_id = 0;
-    if (tid < RB2 && RB2 + tid < NS) next_id = rec[NS - 1 - (RB2 + tid)].id;
     int wave_Lt = last_contributor;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wave_Lt = max(wave_Lt, __shfl_xor(wave_Lt, o, 64));
@@ -225,33 +219,37 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
         }
         TK(2);
         __syncthreads();
-        // ---- B: feature rows (padded to FROW floats), gathered by the ids just staged
+        // ---- B: feature rows (padded to FROW floats), gathered by the ids just staged.  All the loads are issued before
+        // the first LDS write (unconditionally: a clamped row index keeps the address valid) -- written as one guarded
+        // load-then-store per k, hipcc emits a full vmcnt(0) round trip per k.
+        {
+            constexpr int NK = (RB2 * F4 + BATCH - 1) / BATCH;
+            float4 v[NK];
 #pragma unroll
-        for (int k = 0; k < (RB2 * F4 + BATCH - 1) / BATCH; k++) {
-            const int e = tid + BATCH * k;
-            const int g = e / F4, part = e % F4;
-            if (g < nr && !(ablate & 4)) {
-                const size_t gid = (size_t)__float_as_int(s_par[g].q1.w);
+            for (int k = 0; k < NK; k++) {
+                const int e = tid + BATCH * k;
+                const int g = e / F4, part = e % F4;
+                const size_t gid = (size_t)__float_as_int(s_par[g < nr ? g : 0].q1.w);
                 if constexpr (CR == C) {
-                    s_feat4[g * (FROW / 4) + part] = reinterpret_cast<const float4*>(colors + gid * C)[part];
+                    v[k] = reinterpret_cast<const float4*>(colors + gid * C)[part];
                 } else {  // RGB: three floats per Gaussian, the other 13 operand channels are zero
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (part == 0) v = make_float4(colors[gid * 3 + 0], colors[gid * 3 + 1], colors[gid * 3 + 2], 0.f);
-                    s_feat4[g * (FROW / 4) + part] = v;
+                    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (part == 0) v[k] = make_float4(colors[gid * 3 + 0], colors[gid * 3 + 1], colors[gid * 3 + 2], 0.f);
                 }
             }
-        }
-        // The next batch's records (and the prefetch of their feature rows) are requested only now: vmcnt retires in
-        // order, so a request issued before the gather would make the gather wait for it as well.
-        if (tid < RB2 && b0 + RB2 + tid < NS) {
-            cur = rec[NS - 1 - (b0 + RB2 + tid)];
-            const char* row = reinterpret_cast<const char*>(colors + (size_t)next_id * CR);
+            // pins every loaded value in registers here: hipcc otherwise sinks each load into the guarded store below
+            #pragma unroll
+            for (int k = 0; k < NK; k++) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
 #pragma unroll
-            for (int o = 0; o < CR * 4; o += 128)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + o),
-                                                 (__attribute__((address_space(3))) void*)s_dump, 4, 0, 0);
+            for (int k = 0; k < NK; k++) {
+                const int e = tid + BATCH * k;
+                const int g = e / F4, part = e % F4;
+                if (g < nr && !(ablate & 4)) s_feat4[g * (FROW / 4) + part] = v[k];
+            }
         }
-        if (tid < RB2 && b0 + 2 * RB2 + tid < NS) next_id = rec[NS - 1 - (b0 + 2 * RB2 + tid)].id;
+        // The next batch's records are requested only now: vmcnt retires in order, so a request issued before the
+        // gather would make the gather wait for it as well.
+        if (tid < RB2 && b0 + RB2 + tid < NS) cur = rec[NS - 1 - (b0 + RB2 + tid)];
         __syncthreads();
 
         // ---- this quadrant's rows, back to front, restricted to positions below the quadrant's max n_contrib;

@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
     const uint32_t px = blockIdx.x * TILE_X + (wave & 1) * 8 + (lane & 7);
     const uint32_t py = blockIdx.y * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
     const uint32_t pix_id = W * py + px;
-    const float pixfx = (float)px, pixfy = (float)py;
+    float pixfx = (float)px, pixfy = (float)py;
+    asm volatile("" : "+v"(pixfx), "+v"(pixfy));  // opaque: hipcc otherwise re-converts both in every iteration of the blend loop
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     bool done = !inside;
 
@@ -113,7 +114,9 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
         // ---- A: this batch's records -> LDS; next batch's records -> registers (in flight during B and C)
         if (tid < nb) {
             s_xy[tid] = cur.xy;
-            s_co[tid] = cur.co;
+            // conic pre-scaled to (-a/2, -b, -c/2): power = ((-a/2 dx) dx + (-c/2 dy) dy) + (-b dx) dy is bit-identical to the
+            // reference's -0.5f (a dx dx + c dy dy) - b dx dy (scaling by -1/2 and -1 commutes with every rounding)
+            s_co[tid] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
             s_id[tid] = cur.id;
             s_pm[tid] = cur.pm;
             if constexpr (!VEC_STAGE) {
@@ -138,12 +141,26 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
             // would put one more ~4 us dependent access in front of every batch)
             __syncthreads();
             constexpr int F4 = C / 4;  // float4s per Gaussian
-            if (!(ablate & 4))
+            // All the loads are issued before the first LDS write (unconditionally: a clamped row index keeps the
+            // address valid) -- written as one guarded load-then-store per k, hipcc emits a full vmcnt(0) round trip per k.
+            if (!(ablate & 4)) {
+                constexpr int NK = FB * F4 / BATCH;
+                float4 v[NK];
 #pragma unroll
-            for (int k = 0; k < FB * F4 / BATCH; k++) {
-                const int q = tid + BATCH * k;
-                const int g = q / F4, part = q % F4;
-                if (g < nb) s_feat4[g * F4 + part] = reinterpret_cast<const float4*>(features + (size_t)s_id[g] * C)[part];
+                for (int k = 0; k < NK; k++) {
+                    const int q = tid + BATCH * k;
+                    const int g = q / F4, part = q % F4;
+                    v[k] = reinterpret_cast<const float4*>(features + (size_t)s_id[g < nb ? g : 0] * C)[part];
+                }
+                // pins every loaded value in registers here: hipcc otherwise sinks each load into the guarded store below
+                #pragma unroll
+                for (int k = 0; k < NK; k++) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+                    const int q = tid + BATCH * k;
+                    const int g = q / F4, part = q % F4;
+                    if (g < nb) s_feat4[g * F4 + part] = v[k];
+                }
             }
         }
         __syncthreads();
@@ -170,6 +187,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
             float4 nco = s_co[k < 0 ? 0 : k];
             uint32_t npm = s_pm[k < 0 ? 0 : k];
             bool finished = false;
+            uint64_t live = ballot64(!done);  // lanes still blending (wave-uniform copy of !done: the loop exit needs no ballot)
             uint32_t last_pm = 0;
             int last_k = 0;
             while (k >= 0 && !finished) {
@@ -183,11 +201,14 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
                 nco = s_co[kp];
                 npm = s_pm[kp];
                 const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
-                const float power = -0.5f * (cco.x * dx * dx + cco.z * dy * dy) - cco.y * dx * dy;
-                const float alpha = fminf(0.99f, cco.w * __expf(power));
-                const bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                const float power = (cco.x * dx * dx + cco.z * dy * dy) + cco.y * dx * dy;
+                const float t = cco.w * __expf(power);
+                const float alpha = fminf(0.99f, t);
+                const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);  // min(0.99, t) >= 1/255  <=>  t >= 1/255
                 const float test_T = T * (1 - alpha);
-                const bool stop = ok && test_T < 0.0001f;
+                // forward.cu:358-362: the pixel is done once a contributor would push T below 1e-4 (that one is not blended)
+                const bool stop = (ok ? test_T : 1.0f) < 0.0001f;
+                live &= ~ballot64(stop);
                 done = done || stop;
                 const bool blend = ok && !stop;
                 const float w = blend ? alpha * T : 0.f;
@@ -210,7 +231,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
                 }
                 T = blend ? test_T : T;
                 last_contributor = blend ? (pm >> 4) + 1u : last_contributor;
-                finished = ballot64(!done) == 0;  // this wave is finished
+                finished = live == 0;  // this wave is finished
                 last_pm = pm;
                 last_k = k;
                 k = kn;

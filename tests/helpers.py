@@ -261,7 +261,7 @@ def compare_lean_with_full(inp, full: GpuRun, dL=None, dLm=None, full_grads=None
     if dL is not None:
         g = lean.backward(dL, dLm)
         for k, want in full_grads.items():
-            assert_close(k + " (lean vs full)", g[k], want, rtol=1e-4)  # same sums, different atomic order
+            assert_close(k + " (lean vs full)", g[k], want, rtol=1e-4, flip_frac=GRAD_FLIP_FRAC)  # same sums, different atomic order
     return lean
 
 
