@@ -251,7 +251,9 @@ inline int bin_workgroups(int P)
 // FULL (emit pass): every overlap is stored, culled ones with mask 0 -- the per-tile sort then reproduces the reference's
 // point_list.  !FULL ("lean", the default of the product path): `entries` was zero-filled and only the overlaps that
 // pass the cull are stored (a third of them; non-zero because their mask is), at the front of the slice's share of
-// the tile's segment; the per-tile sort drops the zeros and never materialises point_list.
+// the tile's segment; the per-tile sort drops the zeros and never materialises point_list.  Both passes then walk
+// only the part of each rect that the cull can keep (shrink_rect): counts, ranges and segments are upper bounds of
+// the lean lists, not the reference's.
 template <bool EMIT, bool FULL = true>
 __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
                                                                 uint32_t* __restrict__ partial,
@@ -283,6 +285,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
             const int rad = (int)rec.pm;
             if (rad > 0) {
                 getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
+                if (!FULL) shrink_rect(rec.xy, rec.co, rad, rmin, rmax);  // count and emit pass alike
                 count = (rmax.x - rmin.x) * (rmax.y - rmin.y);
             }
             if (EMIT) {

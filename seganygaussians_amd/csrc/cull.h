@@ -47,6 +47,40 @@ __device__ __forceinline__ bool tile_may_blend(float2 xy, float4 co, float tile_
     return !(qmin > tau + 1e-5f * mag + 1e-4f);
 }
 
+// Lean lists: the part of a Gaussian's reference tile rect [rmin, rmax) in which tile_may_blend can return true at all.
+// A tile is kept only if the minimum of q over it is <= tau + (its margin); every margin of the rect is below
+// 1e-5 mag_max + 1e-4 with mag_max taken at the largest |d| the rect reaches (radius + 15 px), so every kept tile
+// meets the ellipse { q <= tau_big }, hence its axis-aligned bounding box |dx| <= sqrt(2 tau_big C / det),
+// |dy| <= sqrt(2 tau_big A / det).  The 3-sigma SQUARE of the reference is about twice that area on the benchmark scene.
+// Slack (3x the margin, 0.1 % + 0.01 px on the extents) dwarfs the float rounding of both sides: a strict superset.
+__device__ __forceinline__ void shrink_rect(float2 xy, float4 co, int rad, uint2& rmin, uint2& rmax)
+{
+    const float A = co.x, B = co.y, C = co.z, o = co.w;
+    if (!(o >= (1.0f / 255.0f))) {  // tile_may_blend is false everywhere
+        rmax = rmin;
+        return;
+    }
+    const float det = A * C - B * B;
+    if (!(A > 0.f && C > 0.f && det > 0.f)) return;  // not positive definite: no culling
+    const float m = (float)rad + 16.0f;
+    const float mag_max = (0.5f * (A + C) + fabsf(B)) * m * m;
+    const float tau_big = __logf(255.0f * o) + 3e-5f * mag_max + 2e-4f;
+    const float s = 2.0f * tau_big * __builtin_amdgcn_rcpf(det);
+    const float ex = sqrtf(s * C) * 1.001f + 0.01f, ey = sqrtf(s * A) * 1.001f + 0.01f;
+    if (!(ex < 1e9f && ey < 1e9f)) return;  // overflow / NaN: keep the rect
+    // tile column tx holds pixels 16 tx .. 16 tx + 15: it meets [x - ex, x + ex] iff tx >= (x - ex - 15) / 16 and tx <= (x + ex) / 16
+    const float lx = floorf((xy.x - ex - 15.0f) * (1.0f / 16.0f)), hx = floorf((xy.x + ex) * (1.0f / 16.0f)) + 1.0f;
+    const float ly = floorf((xy.y - ey - 15.0f) * (1.0f / 16.0f)), hy = floorf((xy.y + ey) * (1.0f / 16.0f)) + 1.0f;
+    const float fx0 = fmaxf((float)rmin.x, lx), fx1 = fminf((float)rmax.x, hx);
+    const float fy0 = fmaxf((float)rmin.y, ly), fy1 = fminf((float)rmax.y, hy);
+    if (!(fx1 > fx0 && fy1 > fy0)) {
+        rmax = rmin;
+        return;
+    }
+    rmin = make_uint2((uint32_t)fx0, (uint32_t)fy0);
+    rmax = make_uint2((uint32_t)fx1, (uint32_t)fy1);
+}
+
 // Bit q (= qy*2 + qx) set  <=>  the 8x8 pixel quadrant q of the tile at (tile_px, tile_py) may receive
 // alpha >= 1/255 from this Gaussian.  xy: pixel-space mean; co: conic (A,B,C) + opacity.
 __device__ __forceinline__ uint32_t quadrant_mask(float2 xy, float4 co, float tile_px, float tile_py)

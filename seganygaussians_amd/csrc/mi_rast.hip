@@ -17,6 +17,7 @@
 #include "blend_bwd.h"
 #include "blend_bwd_mfma.h"
 #include "blend_fwd.h"
+#include "blend_fwd_x3.h"
 #include "common.h"
 #include "geometry.h"
 
@@ -309,6 +310,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -346,13 +348,20 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                            geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
     }
     STAGE_CHECK("depth sort");
+    // Full lists (the reference's point_list and full-list positions) are materialised on request -- the reference's
+    // `debug` flag or mi_rast_set_full_lists(1) -- ; otherwise only the overlaps that pass the cull are listed.
+    const bool full = debug != 0 || g_full_lists != 0;
     const int nwg = bin_workgroups(P);
     const size_t bin_lds = ((size_t)((ntiles + 3) & ~3) + 3 * 1024 + 16) * sizeof(uint32_t);
     {
         // count pass over rank slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
         StageTimer t(stream, MI_STAGE_TILE_SCAN);
-        hipLaunchKernelGGL(bin_ranks_kernel<false>, dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
-                           img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
+        if (full)
+            hipLaunchKernelGGL((bin_ranks_kernel<false, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+                               img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
+        else
+            hipLaunchKernelGGL((bin_ranks_kernel<false, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+                               img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)ntiles + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
@@ -376,9 +385,6 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     char* bin_base = binning_buffer(bin_size, binning_user);
     if (!bin_base) return fail(MI_RAST_ERR_ALLOC, "binning buffer callback returned NULL");
     bin = bin_from(bin_base, R);
-    // Full lists (the reference's point_list and full-list positions) are materialised on request -- the reference's
-    // `debug` flag or mi_rast_set_full_lists(1) -- ; otherwise only the overlaps that pass the cull are listed.
-    const bool full = debug != 0 || g_full_lists != 0;
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
@@ -414,7 +420,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     } while (0)
             LAUNCH_TILE_SORT(0, 2048, false, 256);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
-            if (g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R)
+            // lean lists: the counts are those of the shrunk rects, an upper bound of the lists and a lower bound of R
+            if (full ? g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R : g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] > R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
             if (max_tile_count > 2048) LAUNCH_TILE_SORT(2048, 6144, false, 1024);
@@ -638,7 +645,12 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
         StageTimer t(stream, MI_STAGE_BLEND_FWD);
         if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth);
         else if (channels == 3) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
-        else if (channels == 32) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+        else if (channels == 32 && (g_ablate_fwd & 2048))  // f32-MFMA forward (MI_RAST_ABLATE_FWD=2048: comparisons)
+            launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+        else if (channels == 32)
+            hipLaunchKernelGGL(blend_fwd_x3_kernel, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
+                               img.blend_count, vp.W, vp.H, feature_ptr, img.final_T, img.n_contrib, img.tile_consumed,
+                               img.tile_nsurv, background, out_color);
         else launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
     }
     STAGE_CHECK("render");
