@@ -223,6 +223,10 @@ def main():
             "config": {"workload": f"BASELINE {args.config}: {P} Gaussians, {W}x{H}, {C}-D features, fwd+bwd, "
                                    f"1 view/GPU/step" + (", RCCL all-reduce of (P,C) feature grads" if world > 1 else ""),
                        "parallelism": f"view-sharded x{world}", "counters": counters,
+                       "lists": "lean (product default: only overlaps that pass the exact-conservative cull are listed; "
+                                "counters E/L from one full-list call)",
+                       "arithmetic": "f32 throughout; C=32 forward accumulation = exact 3-way bf16 split of f32 operands, "
+                                     "six partial products on the bf16 matrix pipe, f32 accumulate (f32 rounding level)",
                        "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()}},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

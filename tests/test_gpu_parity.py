@@ -61,6 +61,30 @@ def test_features32_dense():
     assert c["E"] < c["R"], "scene should exercise early termination"
 
 
+def test_features32_forward_x3_matches_f32_mfma(monkeypatch):
+    """The default 32-channel forward accumulates on the bf16 matrix pipe with exactly split operands (blend_fwd_x3.h);
+    MI_RAST_ABLATE_FWD=2048 selects the f32-MFMA kernel (a bit-exact fmaf chain).  Same lists, same alpha / T / n_contrib
+    (bit-identical), and images that differ by rounding of the f32 accumulation only (a few ulp; same distance from the
+    fp64-accumulating oracle)."""
+    inp = hp.make_inputs(60_000, 640, 360, 32, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
+    x3 = hp.GpuRun(inp).forward()
+    monkeypatch.setenv("MI_RAST_ABLATE_FWD", "2048")
+    f32 = hp.GpuRun(inp).forward()
+    monkeypatch.delenv("MI_RAST_ABLATE_FWD")
+    a, b = x3.color.cpu().numpy().astype(np.float64), f32.color.cpu().numpy().astype(np.float64)
+    assert not np.array_equal(a, b), "expected two different kernels (is the switch still wired?)"
+    scale = np.abs(b).max()
+    assert np.abs(a - b).max() <= 2e-6 * scale, (np.abs(a - b).max(), scale)  # a few ulp of the accumulated sums
+    # against the fp64-accumulating oracle both sit at the f32 rounding level (measured RMS: 2.1e-8 vs 0.7e-8 at an image
+    # scale of 0.5 -- the MFMA rounds its 16-product partial sums differently from sixteen chained fmaf)
+    ref = so.forward(inp).color.astype(np.float64)
+    rms_a, rms_b = np.sqrt(((a - ref) ** 2).mean()), np.sqrt(((b - ref) ** 2).mean())
+    assert rms_a <= 1e-7 * scale and rms_b <= 1e-7 * scale, (rms_a, rms_b, scale)
+    ia, ib = x3.img_fields(), f32.img_fields()
+    np.testing.assert_array_equal(ia["final_T"].view(np.uint32), ib["final_T"].view(np.uint32))
+    np.testing.assert_array_equal(ia["n_contrib"], ib["n_contrib"])
+
+
 def test_features32_odd_size_random_bg():
     """Image size not a multiple of 16: edge tiles with pixels outside the image (forward.cu:288-290,378)."""
     inp = hp.make_inputs(8_000, 203, 117, 32, seed=4, bg="random", camera="orbit")
