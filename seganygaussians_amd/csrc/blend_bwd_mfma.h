@@ -35,19 +35,23 @@ constexpr int DLROW = 33;  // padded gradient-image staging row (floats; 32 chan
 // padded feature row (floats; conflict-free 16-lane b128 operand reads), waves per SIMD the registers allow.
 template <int C>
 struct BwdCfg {
-    static constexpr int RB2 = C == 32 ? 80 : 128;  // C == 16 is the RGB kernel (3 real channels padded to one MFMA block)
+    static constexpr int RB2 = C == 32 ? 64 : 128;  // C == 16 is the RGB kernel (3 real channels padded to one MFMA block)
     static constexpr int FROW = C + 4;
     static constexpr int NBITS = (RB2 + 63) / 64;
     static constexpr int FEAT4 = (RB2 + 1) * FROW / 4;  // + one all-zero row for the list padding
     static constexpr int POOL4 = FEAT4 + 2 * 4 * CHK * WROW / 4;
     static constexpr int WAVES = C == 64 ? 2 : 3;
+    // C = 32: the feature rows of the NEXT batch are requested while this batch is processed (ids fetched a batch earlier
+    // still) and wait in registers, so no batch stops for a dependent global access.  What pays for the 10 registers:
+    // records are fetched as 8-byte quarters by all 256 threads (2 registers instead of 8), S is read row by row.
+    static constexpr bool PIPE = C == 32;
     static_assert(POOL4 * 4 >= 4 * 64 * DLROW, "gradient-image staging must fit in the aliased buffers");
     static_assert(RB2 + FROW / 4 <= 256, "staging roles are assigned by thread index");
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// One staged record: {x, y, -a/2, -b} {-c/2, opacity, list position (int bits), Gaussian id (int bits)} with the conic
+// One staged record: {x, y, -a/2, -b} {-c/2, opacity, list position << 4 | quadrant mask (int bits), Gaussian id (int bits)} with the conic
 // (a, b, c) pre-scaled so that power = ((-a/2 dx) dx + (-c/2 dy) dy) + (-b dx) dy -- bit-identical to the reference
 // expression -0.5f (a dx dx + c dy dy) - b dx dy (scaling by -1/2 and -1 commutes with every rounding), two VALU fewer.
 struct BwdPar {
@@ -117,8 +121,23 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
         else dLpix[ch] = 0.f;
     }
     const BlendRec* rec = blend_rec + range.x;
+    constexpr bool PIPE = BwdCfg<C>::PIPE;
+    constexpr int NK = (RB2 * (C / 4) + BATCH - 1) / BATCH;  // float4 feature gathers per thread and batch
+    static_assert(!PIPE || RB2 * 4 == BATCH, "PIPE: one 8-byte record quarter per thread");
     BlendRec cur;
-    if (tid < RB2 && tid < NS) cur = rec[NS - 1 - tid];
+    uint2 curq = make_uint2(0u, 0u);  // PIPE: quarter (tid & 3) of record (tid >> 2) of the batch
+    float4 featpf[PIPE ? NK : 1];     // PIPE: this thread's parts of the next batch's feature rows
+    uint32_t nid[PIPE ? NK : 1];      // PIPE: Gaussian ids of the batch after that
+    if constexpr (PIPE) {
+        if ((tid >> 2) < NS) curq = reinterpret_cast<const uint2*>(rec + (NS - 1 - (tid >> 2)))[tid & 3];
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int g = (tid + BATCH * k) / (C / 4);
+            nid[k] = (g < RB2 && g < NS) ? rec[NS - 1 - g].id : 0u;
+        }
+    } else {
+        if (tid < RB2 && tid < NS) cur = rec[NS - 1 - tid];
+    }
     int wave_Lt = last_contributor;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wave_Lt = max(wave_Lt, __shfl_xor(wave_Lt, o, 64));
@@ -170,6 +189,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     }
     TK(1);
     const float nTb = -T_final * bg_dot_dpixel;  // the background term of dL/dalpha is nTb / (1 - alpha)
+    const int last4 = last_contributor << 4, wave_Lt4 = wave_Lt << 4;  // compared with (position << 4 | mask)
 
     // Phi[pixel 16kq+s][j = n16] = monomial j (1, x, y, x^2, xy, y^2) about the quadrant centre, x = (s&7) - 3.5 (a
     // literal per unrolled step), y = 2kq - 3.5 + (s>>3):  phi = P[s>>3] + Q[s>>3] x + R x^2  (exact: small dyadics)
@@ -194,22 +214,78 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     float* my_mom = reinterpret_cast<float*>(s_mom4[wave]);
     const char* const par_bytes = reinterpret_cast<const char*>(s_par);
 
+    if constexpr (PIPE) {  // first batch's feature parts, second batch's ids
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int e = tid + BATCH * k;
+            const int g = e / F4, part = e % F4;
+            featpf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < RB2 && g < NS) featpf[k] = reinterpret_cast<const float4*>(colors + (size_t)nid[k] * C)[part];
+        }
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int g = (tid + BATCH * k) / F4;
+            if (g < RB2 && RB2 + g < NS) nid[k] = rec[NS - 1 - (RB2 + g)].id;
+        }
+    }
     for (int b0 = 0; b0 < NS; b0 += RB2) {
         const int nr = min(RB2, NS - b0);  // records in this batch, walked back to front
         TK(4);
         __syncthreads();                   // LDS reuse (first batch: the gradient-image staging reads are done)
         // ---- A: records -> LDS; next batch's record -> registers; quadrant bitmaps
-        if (tid < nr) {
+        if constexpr (PIPE) {
+            // Staging indices and addresses are derived from an opaque copy of the thread index: hipcc otherwise keeps a
+            // dozen of them live across the chunk loop, spills them, and every reload (scratch shares vmcnt) stalls the
+            // requests below one by one.
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            // quarter 0 = {x, y} -> bytes 0..7; 1 = {id, pm} -> {pm, id} at 24; 2 = {a, b} -> {-a/2, -b} at 8; 3 = {c, opacity} -> {-c/2, opacity} at 16
+            const int rq = tid >> 2, qq = tid & 3;
+            if (rq < nr) {
+                float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
+                if (qq == 1) v = make_float2(__uint_as_float(curq.y), __uint_as_float(curq.x));
+                if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
+                if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
+                const int dst = qq == 0 ? 0 : (qq == 1 ? 24 : (qq == 2 ? 8 : 16));
+                *reinterpret_cast<float2*>(reinterpret_cast<char*>(&s_par[rq]) + dst) = v;
+            }
+#pragma unroll
+            for (int k = 0; k < NK; k++) {  // this batch's feature rows arrive from registers
+                const int e = tid + BATCH * k;
+                const int g = e / F4, part = e % F4;
+                if (g < nr) s_feat4[g * (FROW / 4) + part] = featpf[k];
+            }
+            // Requests for the next batch (feature rows: ids known; records) and the ids of the one after.  The ids are
+            // the youngest loads of the previous round: they are consumed (one wait, long satisfied) before anything
+            // new is requested, so that nothing below waits on a request of this round.
+            uint32_t idk[NK];
+#pragma unroll
+            for (int k = 0; k < NK; k++) idk[k] = nid[k];
+#pragma unroll
+            for (int k = 0; k < NK; k++) asm volatile("" : "+v"(idk[k]));
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const int e = tid + BATCH * k;
+                const int g = e / F4, part = e % F4;
+                if (g < RB2 && b0 + RB2 + g < NS) featpf[k] = reinterpret_cast<const float4*>(colors + (size_t)idk[k] * C)[part];
+            }
+            if (b0 + RB2 + rq < NS) curq = reinterpret_cast<const uint2*>(rec + (NS - 1 - (b0 + RB2 + rq)))[qq];
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const int g = (tid + BATCH * k) / F4;
+                if (g < RB2 && b0 + 2 * RB2 + g < NS) nid[k] = rec[NS - 1 - (b0 + 2 * RB2 + g)].id;
+            }
+        } else if (tid < nr) {
             s_par[tid].q0 = make_float4(cur.xy.x, cur.xy.y, -0.5f * cur.co.x, -cur.co.y);
-            s_par[tid].q1 = make_float4(-0.5f * cur.co.z, cur.co.w, __int_as_float((int)(cur.pm >> 4)), __int_as_float((int)cur.id));
+            s_par[tid].q1 = make_float4(-0.5f * cur.co.z, cur.co.w, __int_as_float((int)cur.pm), __int_as_float((int)cur.id));
         }
-        if (tid == RB2) {  // padding record: never valid ...
+        if ((!PIPE || b0 == 0) && tid == RB2) {  // padding record: never valid ...
             s_par[RB2].q0 = make_float4(0.f, 0.f, -0.5f, 0.f);
-            s_par[RB2].q1 = make_float4(-0.5f, 0.f, __int_as_float(0x7fffffff), __int_as_float(0));
+            s_par[RB2].q1 = make_float4(-0.5f, 0.f, __int_as_float(0x7ffffff0), __int_as_float(0));
         }
-        if (tid >= 256 - FROW / 4)  // ... and its all-zero feature row (S = 0)
+        if ((!PIPE || b0 == 0) && tid >= 256 - FROW / 4)  // ... and its all-zero feature row (S = 0)
             s_feat4[RB2 * (FROW / 4) + (tid - (256 - FROW / 4))] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (wave < NBITS) {
+        if (!PIPE && wave < NBITS) {
             const uint32_t pmv = tid < nr ? cur.pm : 0u;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -222,8 +298,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
         // ---- B: feature rows (padded to FROW floats), gathered by the ids just staged.  All the loads are issued before
         // the first LDS write (unconditionally: a clamped row index keeps the address valid) -- written as one guarded
         // load-then-store per k, hipcc emits a full vmcnt(0) round trip per k.
-        {
-            constexpr int NK = (RB2 * F4 + BATCH - 1) / BATCH;
+        if constexpr (!PIPE) {
             float4 v[NK];
 #pragma unroll
             for (int k = 0; k < NK; k++) {
@@ -249,8 +324,8 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
         }
         // The next batch's records are requested only now: vmcnt retires in order, so a request issued before the
         // gather would make the gather wait for it as well.
-        if (tid < RB2 && b0 + RB2 + tid < NS) cur = rec[NS - 1 - (b0 + RB2 + tid)];
-        __syncthreads();
+        if (!PIPE && tid < RB2 && b0 + RB2 + tid < NS) cur = rec[NS - 1 - (b0 + RB2 + tid)];
+        if constexpr (!PIPE) __syncthreads();
 
         // ---- this quadrant's rows, back to front, restricted to positions below the quadrant's max n_contrib;
         //      the list is padded with CHK references to the padding record
@@ -258,7 +333,8 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
 #pragma unroll
         for (int h = 0; h < NBITS; h++) {
             const int ridx = 64 * h + lane;
-            const bool cand = ((s_bits[wave][h] >> lane) & 1ull) && ridx < nr && __float_as_int(s_par[ridx < nr ? ridx : 0].q1.z) < wave_Lt;
+            const int pmv = __float_as_int(s_par[ridx < nr ? ridx : 0].q1.z);
+            const bool cand = (PIPE ? ((pmv >> wave) & 1) != 0 : ((s_bits[wave][h] >> lane) & 1ull) != 0) && ridx < nr && pmv < wave_Lt4;
             const uint64_t b = ballot64(cand);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
             if (cand) s_list[wave][cnt + below] = (uint32_t)(ridx * sizeof(BwdPar));
@@ -296,15 +372,12 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
             // holds row 4g+r of pixel 16pb+p in sacc[pb][r]; both the writes and the row reads are conflict-free
             // (row stride 68 floats).  (A register-only v_permlane16/32_swap transpose is 16 instructions, but
             // hipcc 7.2 miscompiles that builtin sequence -- tools/s_probe.hip -- so LDS it is.)
-            float Srow[16];
+            // Row m of S is read when step 2 reaches row m, just before w of the same row overwrites it (same address).
             {
 #pragma unroll
                 for (int pb = 0; pb < 4; pb++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) my_wa[(4 * kq + r) * WROW + 16 * pb + n16] = sacc[pb][r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-                for (int m = 0; m < 16; m++) Srow[m] = my_wa[m * WROW + lane];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
 
@@ -321,7 +394,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 const float G = __expf(power);
                 // opacity * G where the row can blend into this pixel at all, else 0; the 1/255 cut is the last test so
                 // that its compare doubles as the ballot (min(0.99, t) >= 1/255  <=>  t >= 1/255)
-                const float t0 = ((__float_as_int(p1.z) < last_contributor) && power <= 0.0f) ? p1.y * G : 0.f;
+                const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;
                 const bool valid = t0 >= (1.0f / 255.0f);
                 const float tG = valid ? t0 : 0.f;   // opacity * G of a contributing row
                 const float alpha = fminf(0.99f, tG);
@@ -329,7 +402,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 const float inv = __builtin_amdgcn_rcpf(om);
                 T = T * inv;
                 const float w = alpha * T;  // dchannel_dcolor
-                const float dS = Srow[rr] - Rcur;
+                const float dS = my_wa[rr * WROW + lane] - Rcur;
                 const float dL_dalpha = fmaf(nTb, inv, dS * T);
                 Rcur = fmaf(alpha, dS, Rcur);  // = alpha S + (1 - alpha) Rcur
                 const float u = tG * dL_dalpha;  // dL/dG * G  (dL/dG = opacity * dL/dalpha, clamp ignored as in the reference)

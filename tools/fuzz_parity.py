@@ -31,7 +31,11 @@ def one_case(rng, k):
         m = np.ascontiguousarray(inp.means3D, np.float32)
         m[: P // 2, 2] = np.float32(rng.uniform(2.0, 6.0))
         inp.means3D = m
-    desc = f"case {k}: C={C} {W}x{H} P={P} " + " ".join(f"{a}={b}" for a, b in kw.items() if a != "seed")
+    opa_scale = 1.0
+    if rng.random() < 0.4:   # faint Gaussians: small cut-off ellipses (cull.h shrink_rect), some below 1/255 altogether
+        opa_scale = float(rng.choice([0.3, 0.05, 0.01]))
+        inp.opacities = (np.asarray(inp.opacities, np.float32) * np.float32(opa_scale)).astype(np.float32)
+    desc = f"case {k}: C={C} {W}x{H} P={P} opa_scale={opa_scale} " + " ".join(f"{a}={b}" for a, b in kw.items() if a != "seed")
     one_case.desc = desc
     gpu = hp.GpuRun(inp).forward()
     fwd = so.forward(inp)
@@ -42,6 +46,7 @@ def one_case(rng, k):
     grads = gpu.backward(dL, dLm)
     bwd = so.backward(inp, fwd, dL, None if dLm is None else dLm[0])
     hp.compare_gradients(grads, bwd)
+    hp.compare_lean_with_full(inp, gpu, dL, dLm, grads)   # the product default: identical blend lists and images
     return desc, fwd.num_rendered
 
 
