@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override Gaussian count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--dist-single", action="store_true",
+                    help="testing only: initialise torch.distributed (RCCL) with a single rank and run the N > 1 step")
     args = ap.parse_args()
 
     import numpy as np
@@ -74,15 +76,17 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_single:
         import torch.distributed as dist
+        if args.dist_single and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from seganygaussians_amd import _lib, install_dropin, scenes
     install_dropin()
     from diff_gaussian_rasterization_contrastive_f import GaussianRasterizationSettings
-    from seganygaussians_amd.dist import allreduce_grads
-    from seganygaussians_amd.rasterizer import make_rasterizer
+    from seganygaussians_amd.dist import allreduce_grads_async
+    from seganygaussians_amd.rasterizer import make_rasterizer, set_features_ready_event
 
     cfg = scenes.CONFIGS[args.config]
     C, W, H = cfg["C"], cfg["W"], cfg["H"]
@@ -111,16 +115,25 @@ def main():
     def step():
         for l in leaves:
             l.grad = None
+        # config 4: the features of this step are "ready" when the previous step's gradient all-reduce is (in training the
+        # optimizer step sits between the two).  Only the blend stage of the forward reads them; the geometry stages of this
+        # view -- SAGA trains the feature rows alone, scene/gaussian_model_ff.py:154-162 -- run while the gradients travel.
+        ev, _keep = state.pop("pending", (None, None))
+        if ev is not None:
+            set_features_ready_event(ev)
         means2D = torch.zeros_like(means3D, requires_grad=True)
         color, radii = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=feats, opacities=opac,
                                   scales=scales, rotations=rots, cov3D_precomp=None)
         torch.autograd.backward(color, grad_tensors=dL)
         if dist is not None:
-            # config 4: sum the per-Gaussian feature gradients of the N views over RCCL/xGMI (one flat 128-MB bucket)
-            allreduce_grads([feats.grad])
+            # sum the per-Gaussian feature gradients of the N views over RCCL/xGMI: one flat 128-MB bucket, asynchronous
+            state["pending"] = allreduce_grads_async([feats.grad])
         state["radii"] = radii
 
     def barrier():
+        ev, _keep = state.pop("pending", (None, None))
+        if ev is not None:
+            ev.synchronize()  # the last step's all-reduce belongs to the timed region
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -230,9 +243,18 @@ def main():
                        "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()}},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which reaches a redirected stdout only when it is flushed: do that
+        # first, so that the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

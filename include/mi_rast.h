@@ -156,6 +156,12 @@ uint32_t mi_rast_get_higher_msb(uint32_t n);
  *    and full-list positions, so that the integer path can be compared bit-exactly with the oracle.  The reference's
  *    `debug` flag implies it for that call. */
 int mi_rast_set_full_lists(int on);
+/* Training loops in which the geometry is frozen and only colors_precomp (the feature rows) is optimised -- SAGA's
+ * contrastive feature training, scene/gaussian_model_ff.py:154-162 -- may start the next forward before the features are
+ * final: preprocess, depth order, binning and the per-tile sort read the geometry only.  The NEXT mi_rast_forward call
+ * makes its stream wait for `hip_event` (a hipEvent_t recorded when colors_precomp is ready, e.g. after the gradient
+ * all-reduce and the optimizer step) right before its blend stage, then forgets the event.  NULL cancels. */
+int mi_rast_set_features_ready_event(void* hip_event);
 
 /* Private-layout maps of the three opaque buffers, so tests can compare the integer path
  * bit-exactly with the oracle.  Each call fills `offsets` (bytes from the buffer start) for the

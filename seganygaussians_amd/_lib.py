@@ -19,7 +19,7 @@ EXPORTS = [
     "mi_rast_forward", "mi_rast_backward", "mi_rast_mark_visible", "mi_rast_mask_forward",
     "mi_rast_mask_backward", "mi_rast_last_error", "mi_rast_version", "mi_rast_supported_channels",
     "mi_rast_get_higher_msb", "mi_rast_geometry_layout", "mi_rast_image_layout", "mi_rast_binning_layout",
-    "mi_rast_profile_enable", "mi_rast_profile_read", "mi_rast_set_full_lists",
+    "mi_rast_profile_enable", "mi_rast_profile_read", "mi_rast_set_full_lists", "mi_rast_set_features_ready_event",
     "mi_knn_smooth_forward", "mi_knn_smooth_backward",  # include/mi_knn_smooth.h
 ]
 
@@ -77,6 +77,8 @@ def load():
     L.mi_rast_profile_enable.argtypes = [i]
     L.mi_rast_set_full_lists.restype = i
     L.mi_rast_set_full_lists.argtypes = [i]
+    L.mi_rast_set_features_ready_event.restype = i
+    L.mi_rast_set_features_ready_event.argtypes = [vp]
     L.mi_rast_profile_read.restype = i
     L.mi_rast_profile_read.argtypes = [C.POINTER(f)]
     u32 = C.c_uint32

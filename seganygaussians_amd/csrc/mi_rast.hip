@@ -256,6 +256,7 @@ BinPtrs bin_from(char* base, int R)
 // Timing experiments only: MI_RAST_ABLATE=<bitmask> disables pieces of the backward blend (results become wrong).
 int g_ablate = 0;
 int g_full_lists = 0;  // mi_rast_set_full_lists
+hipEvent_t g_features_ready = nullptr;  // mi_rast_set_features_ready_event (one-shot)
 int g_ablate_fwd = 0;
 
 bool channels_supported(int c) { return c == 3 || c == 32 || c == 64; }
@@ -512,6 +513,12 @@ int mi_knn_smooth_backward(int P, int C, int K, const int* knn_idx, const int* i
 }
 
 // CF/cuda_rasterizer/rasterizer_impl.cu:35-50
+int mi_rast_set_features_ready_event(void* hip_event)
+{
+    g_features_ready = (hipEvent_t)hip_event;
+    return MI_RAST_OK;
+}
+
 int mi_rast_set_full_lists(int on)
 {
     const int prev = g_full_lists;
@@ -641,6 +648,12 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
     if (rc) return rc;
 
     const float* feature_ptr = colors_precomp != nullptr ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:321
+    if (g_features_ready != nullptr) {
+        // everything above depends on the geometry only; colors_precomp may still be in the making (mi_rast.h)
+        const hipEvent_t ev = g_features_ready;
+        g_features_ready = nullptr;
+        HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+    }
     {
         StageTimer t(stream, MI_STAGE_BLEND_FWD);
         if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth);

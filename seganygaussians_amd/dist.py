@@ -54,6 +54,40 @@ def allreduce_grads(tensors: Sequence[Optional[torch.Tensor]], group=None, avera
             off += n
 
 
+_side_streams = {}
+
+
+def allreduce_grads_async(tensors: Sequence[Optional[torch.Tensor]], group=None):
+    """Starts the in-place SUM all-reduce of contiguous gradient tensors WITHOUT making the current stream wait for it.
+    Returns (event, keepalive): `event` is a torch.cuda.Event that fires when the reduced values are in place (None on
+    CPU tensors, where the call completes the reduction, and when there is nothing to reduce); `keepalive` must be held
+    until the event has been waited for.  Use with rasterizer.set_features_ready_event: in SAGA's feature training the
+    next view's geometry stages (preprocess, depth order, binning, per-tile sort: a quarter of a step) do not depend on
+    the reduced gradients and can run while they travel."""
+    ts = [t for t in tensors if t is not None]
+    if not ts or not (dist.is_available() and dist.is_initialized()):
+        return None, None
+    works = []
+    for t in ts:
+        if not t.is_contiguous():
+            raise ValueError("allreduce_grads_async needs contiguous tensors")
+        works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    if not ts[0].is_cuda:
+        for w in works:
+            w.wait()
+        return None, None
+    dev = ts[0].device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        for w in works:
+            w.wait()  # NCCL/RCCL: the SIDE stream waits for the collective, the host and the compute stream do not
+        ev = torch.cuda.Event()
+        ev.record(side)
+    return ev, (ts, works)
+
+
 class ViewShardedStep:
     """One training iteration over `num_views` views sharded across the ranks.
 

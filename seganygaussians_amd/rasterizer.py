@@ -140,6 +140,14 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
     return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
 
 
+def set_features_ready_event(event) -> None:
+    """The next forward's blend stage waits for `event` (a recorded torch.cuda.Event, or None to cancel); everything
+    before it -- preprocess, depth order, binning, per-tile sort -- only reads the geometry and runs ahead.  For training
+    loops that optimise colors_precomp alone (include/mi_rast.h: mi_rast_set_features_ready_event)."""
+    L = _lib.load()
+    L.mi_rast_set_features_ready_event(None if event is None else C.c_void_p(event.cuda_event))
+
+
 def rasterize_gaussians_backward_native(channels, with_mask_depth, background, means3D, radii, colors, scales,
                                         rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
                                         tan_fovy, dL_dout_color, dL_dout_mask, sh, degree, campos, geomBuffer, R,

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from seganygaussians_amd import scenes
-from seganygaussians_amd.dist import ViewShardedStep, allreduce_grads, views_for_rank
+from seganygaussians_amd.dist import ViewShardedStep, allreduce_grads, allreduce_grads_async, views_for_rank
 
 NUM_VIEWS, P, W, H, C = 5, 400, 64, 48, 32
 
@@ -62,6 +62,11 @@ def _worker(rank, world, port, out_dir):
         t = torch.full((3, 2), float(rank + 1))
         allreduce_grads([t], average=True)
         assert torch.allclose(t, torch.full((3, 2), sum(range(1, world + 1)) / world))
+        # the asynchronous variant (what bench.py overlaps with the next view's geometry stages): on CPU tensors the sum is
+        # complete on return and there is no event to wait for
+        u = torch.full((5,), float(rank + 1))
+        ev, keep = allreduce_grads_async([u, None])
+        assert ev is None and torch.equal(u, torch.full((5,), float(sum(range(1, world + 1)))))
     finally:
         dist.destroy_process_group()
 
@@ -79,6 +84,7 @@ def test_allreduce_is_noop_without_process_group():
     t = torch.ones(4)
     allreduce_grads([t, None])
     assert torch.equal(t, torch.ones(4))
+    assert allreduce_grads_async([t]) == (None, None) and torch.equal(t, torch.ones(4))
 
 
 @pytest.mark.timeout(300)
