@@ -1,4 +1,4 @@
-// blend_fwd_x3.h -- forward blend for C = 32 with the accumulation on the bf16 matrix pipe at f32 accuracy ("bf16x3").
+// blend_fwd_x3.h -- forward blend for C = 32 / 64 with the accumulation on the bf16 matrix pipe at f32 accuracy ("bf16x3").
 //
 // Same algorithm, staging and per-pixel arithmetic as blend_fwd.h (renderCUDA<C> forward, CF/cuda_rasterizer/
 // forward.cu:264-385): alpha, T, the 1/255 and 1e-4 tests, n_contrib and final_T are computed by the same f32 VALU
@@ -26,7 +26,7 @@
 namespace mirast {
 
 constexpr int XB = 128;    // blend-list records per batch
-constexpr int XROW = 192;  // bytes of a staged feature row: bf16 hi[32] | mid[32] | lo[32]
+// a staged feature row: bf16 hi[C] | mid[C] | lo[C], i.e. 6 C bytes (192 at C = 32)
 constexpr int XG = 16;     // Gaussians per MFMA group
 
 // One staged record: {x, y, -a/2, -b} {-c/2, opacity, list position + 1, (position << 4 | quadrant mask)}
@@ -49,13 +49,16 @@ __device__ __forceinline__ void split3_bf16x2(float a, float b, uint32_t& hi, ui
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2fx){sa, sb}, v2bfx));
 }
 
-__global__ void __launch_bounds__(256, 4) blend_fwd_x3_kernel(
+// C = 64: two 32-channel accumulator pairs (64 VGPRs), 24 MFMA per group, rows of 384 bytes: 2 workgroups per CU.
+template <int C>
+__global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
     int W, int H, const float* __restrict__ features, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_consumed, uint32_t* __restrict__ tile_nsurv, const float* __restrict__ bg_color,
     float* __restrict__ out_color)
 {
-    constexpr int C = 32, F4 = C / 4;
+    static_assert(C == 32 || C == 64, "32-channel accumulator blocks");
+    constexpr int F4 = C / 4, NCB = C / 32, XROW = 6 * C, PLANE = 2 * C;  // float4s per row; channel blocks; row / plane bytes
     __shared__ XRec s_rec[XB + 1];   // [XB] = padding record (opacity 0: never blends)
     __shared__ uint32_t s_id[XB];
     __shared__ uint4 s_feat4[(XB + 1) * XROW / 16];    // [XB] = all-zero row
@@ -92,12 +95,14 @@ __global__ void __launch_bounds__(256, 4) blend_fwd_x3_kernel(
     uint32_t last_contributor = 0;
     int consumed = (ballot64(!done) != 0) ? list_len : 0;  // see blend_fwd.h
     int walked = 0;
-    v16f acc0, acc1;  // pixels 0..31 / 32..63 of the quadrant x 32 channels (lane & 31 = channel)
+    v16f acc0[NCB], acc1[NCB];  // pixels 0..31 / 32..63 of the quadrant x channels 32 cb + (lane & 31)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        acc0[r] = 0.f;
-        acc1[r] = 0.f;
-    }
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            acc0[cb][r] = 0.f;
+            acc1[cb][r] = 0.f;
+        }
     const bool lower = lane < 32;
     const int chan2 = 2 * (lane & 31);  // byte offset of this lane's channel inside a bf16 plane
 
@@ -146,8 +151,8 @@ __global__ void __launch_bounds__(256, 4) blend_fwd_x3_kernel(
                     split3_bf16x2(v[k].z, v[k].w, hi.y, mid.y, lo.y);
                     uint2* row = reinterpret_cast<uint2*>(featb + g * XROW);
                     row[part] = hi;
-                    row[8 + part] = mid;
-                    row[16 + part] = lo;
+                    row[F4 + part] = mid;
+                    row[2 * F4 + part] = lo;
                 }
             }
         }
@@ -222,40 +227,43 @@ __global__ void __launch_bounds__(256, 4) blend_fwd_x3_kernel(
                     A0[p] = (v4u){wp[p][0], wp[p][1], wp[p][2], wp[p][3]};
                     A1[p] = (v4u){wp[p][4], wp[p][5], wp[p][6], wp[p][7]};
                 }
-                // -- B operands: lane (channel, k half) gathers the three terms of its 8 entries' feature value
-                v4u B[3];
-                {
-                    const uint4* lp = reinterpret_cast<const uint4*>(&s_list[wave][j0 + (lower ? 0 : 8)]);
-                    const uint4 ka = lp[0], kb = lp[1];
-                    const uint32_t ks[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-                    uint32_t bb[3][4];
-#pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        const char* r0 = featb + ks[2 * d] * (XROW / (int)sizeof(XRec)) + chan2;
-                        const char* r1 = featb + ks[2 * d + 1] * (XROW / (int)sizeof(XRec)) + chan2;
-#pragma unroll
-                        for (int p = 0; p < 3; p++)
-                            bb[p][d] = (uint32_t)*reinterpret_cast<const uint16_t*>(r0 + 64 * p) |
-                                       ((uint32_t)*reinterpret_cast<const uint16_t*>(r1 + 64 * p) << 16);
-                    }
-#pragma unroll
-                    for (int p = 0; p < 3; p++) B[p] = (v4u){bb[p][0], bb[p][1], bb[p][2], bb[p][3]};
-                }
-                // -- six partial products per block, smallest first.  Inline asm with a tied accumulator (see blend_fwd.h);
-                //    s_nop 1 covers VALU-written operands.
+                // -- B operands: lane (channel, k half) gathers the three terms of its 8 entries' feature value, per 32-channel
+                //    block; six partial products per pixel block, smallest first.  Inline asm with a tied accumulator (see
+                //    blend_fwd.h); s_nop 1 covers VALU-written operands.
+                const uint4* lp = reinterpret_cast<const uint4*>(&s_list[wave][j0 + (lower ? 0 : 8)]);
+                const uint4 ka = lp[0], kb = lp[1];
+                const uint32_t ks[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
 #define X3_MFMA(ACC, AP, BP) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(AP), "v"(BP))
-                X3_MFMA(acc0, A0[1], B[1]);
-                X3_MFMA(acc1, A1[1], B[1]);
-                X3_MFMA(acc0, A0[2], B[0]);
-                X3_MFMA(acc1, A1[2], B[0]);
-                X3_MFMA(acc0, A0[0], B[2]);
-                X3_MFMA(acc1, A1[0], B[2]);
-                X3_MFMA(acc0, A0[1], B[0]);
-                X3_MFMA(acc1, A1[1], B[0]);
-                X3_MFMA(acc0, A0[0], B[1]);
-                X3_MFMA(acc1, A1[0], B[1]);
-                X3_MFMA(acc0, A0[0], B[0]);
-                X3_MFMA(acc1, A1[0], B[0]);
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) {
+                    v4u B[3];
+                    {
+                        uint32_t bb[3][4];
+#pragma unroll
+                        for (int d = 0; d < 4; d++) {
+                            const char* r0 = featb + ks[2 * d] * (XROW / (int)sizeof(XRec)) + chan2 + 64 * cb;
+                            const char* r1 = featb + ks[2 * d + 1] * (XROW / (int)sizeof(XRec)) + chan2 + 64 * cb;
+#pragma unroll
+                            for (int p = 0; p < 3; p++)
+                                bb[p][d] = (uint32_t)*reinterpret_cast<const uint16_t*>(r0 + PLANE * p) |
+                                           ((uint32_t)*reinterpret_cast<const uint16_t*>(r1 + PLANE * p) << 16);
+                        }
+#pragma unroll
+                        for (int p = 0; p < 3; p++) B[p] = (v4u){bb[p][0], bb[p][1], bb[p][2], bb[p][3]};
+                    }
+                    X3_MFMA(acc0[cb], A0[1], B[1]);
+                    X3_MFMA(acc1[cb], A1[1], B[1]);
+                    X3_MFMA(acc0[cb], A0[2], B[0]);
+                    X3_MFMA(acc1[cb], A1[2], B[0]);
+                    X3_MFMA(acc0[cb], A0[0], B[2]);
+                    X3_MFMA(acc1[cb], A1[0], B[2]);
+                    X3_MFMA(acc0[cb], A0[1], B[0]);
+                    X3_MFMA(acc1[cb], A1[1], B[0]);
+                    X3_MFMA(acc0[cb], A0[0], B[1]);
+                    X3_MFMA(acc1[cb], A1[0], B[1]);
+                    X3_MFMA(acc0[cb], A0[0], B[0]);
+                    X3_MFMA(acc1[cb], A1[0], B[0]);
+                }
 #undef X3_MFMA
             }
         }
@@ -281,25 +289,28 @@ __global__ void __launch_bounds__(256, 4) blend_fwd_x3_kernel(
     float* tp = reinterpret_cast<float*>(s_feat4) + wave * 8 * 65;
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read
 #pragma unroll
-    for (int part = 0; part < 4; part++) {
-        const int chl = lane & 31;
-        if ((chl >> 3) == part) {
+    for (int cb = 0; cb < NCB; cb++) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int L = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                tp[(chl & 7) * 65 + L] = acc0[r];
-                tp[(chl & 7) * 65 + 32 + L] = acc1[r];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (inside) {
+        for (int part = 0; part < 4; part++) {
+            const int chl = lane & 31;
+            if ((chl >> 3) == part) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int ch = 8 * part + c;
-                out_color[ch * HW + pix_id] = tp[c * 65 + lane] + T * bg_color[ch];
+                for (int r = 0; r < 16; r++) {
+                    const int L = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    tp[(chl & 7) * 65 + L] = acc0[cb][r];
+                    tp[(chl & 7) * 65 + 32 + L] = acc1[cb][r];
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (inside) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int ch = 32 * cb + 8 * part + c;
+                    out_color[ch * HW + pix_id] = tp[c * 65 + lane] + T * bg_color[ch];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
 }
 

@@ -658,13 +658,17 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
         StageTimer t(stream, MI_STAGE_BLEND_FWD);
         if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth);
         else if (channels == 3) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
-        else if (channels == 32 && (g_ablate_fwd & 2048))  // f32-MFMA forward (MI_RAST_ABLATE_FWD=2048: comparisons)
-            launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
-        else if (channels == 32)
-            hipLaunchKernelGGL(blend_fwd_x3_kernel, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
+        else if (g_ablate_fwd & 2048) {  // f32-MFMA forward (MI_RAST_ABLATE_FWD=2048: comparisons)
+            if (channels == 32) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+            else launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+        } else if (channels == 32)
+            hipLaunchKernelGGL(blend_fwd_x3_kernel<32>, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
                                img.blend_count, vp.W, vp.H, feature_ptr, img.final_T, img.n_contrib, img.tile_consumed,
                                img.tile_nsurv, background, out_color);
-        else launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+        else
+            hipLaunchKernelGGL(blend_fwd_x3_kernel<64>, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
+                               img.blend_count, vp.W, vp.H, feature_ptr, img.final_T, img.n_contrib, img.tile_consumed,
+                               img.tile_nsurv, background, out_color);
     }
     STAGE_CHECK("render");
     return MI_RAST_OK;
