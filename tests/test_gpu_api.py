@@ -109,3 +109,35 @@ def test_debug_flag_and_error_snapshot(tmp_path, monkeypatch):
     assert os.path.exists("snapshot_fw.dump")
     dump = torch.load("snapshot_fw.dump", weights_only=False)
     assert len(dump) == 19 and dump[1].shape == (500, 3)
+
+
+def test_features_ready_event_orders_the_blend_stage():
+    """set_features_ready_event: the next forward waits for the event right before its blend stage (and only that
+    forward).  The features are written on a side stream AFTER the forward has been queued; the image must see them."""
+    from seganygaussians_amd.rasterizer import set_features_ready_event
+    mod = __import__("diff_gaussian_rasterization_contrastive_f")
+    dev = torch.device("cuda:0")
+    inp = hp.make_inputs(6000, 208, 144, 32, seed=33, camera="orbit")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    means3D, opac, scales, rots = t(inp.means3D), t(inp.opacities), t(inp.scales), t(inp.rotations)
+    final = t(inp.colors_precomp)
+    rast = mod.GaussianRasterizer(raster_settings=_settings(mod, inp, dev))
+    kw = dict(means3D=means3D, means2D=torch.zeros_like(means3D), shs=None, opacities=opac, scales=scales,
+              rotations=rots, cov3D_precomp=None)
+    with torch.no_grad():
+        want, _ = rast(colors_precomp=final, **kw)
+        feats = torch.zeros_like(final)          # not ready yet
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            big = torch.empty(64 << 20, device=dev)
+            for _ in range(8):                    # keep the side stream busy for a while before the copy
+                big.normal_()
+            feats.copy_(final)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        set_features_ready_event(ev)
+        got, _ = rast(colors_precomp=feats, **kw)
+        again, _ = rast(colors_precomp=feats, **kw)   # the event was consumed: plain call
+    torch.cuda.synchronize(dev)
+    assert torch.equal(got, want) and torch.equal(again, want)
