@@ -290,7 +290,6 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
         HIP_TRY(hipMemsetAsync(img.num_rendered, 0, R_SLOTS * R_SLOT_STRIDE * sizeof(int), stream));
-        HIP_TRY(hipMemsetAsync(img.blend_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
@@ -430,6 +429,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
 #undef LAUNCH_TILE_SORT
         }
         STAGE_CHECK("tile sort");
+    } else {
+        // no overlap at all: the per-tile sort, which writes every tile's blend_count otherwise, does not run
+        HIP_TRY(hipMemsetAsync(img.blend_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
     }
     return MI_RAST_OK;
 }
