@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
                 int fin_j = -1;
 #pragma unroll
                 for (int i = 0; i < XG / 2; i++) {
-                    if (j0 + 2 * i >= cnt) {  // padding pair of the batch's last group (wave-uniform): w = 0
+                    if (j0 + 2 * i >= cnt || live == 0) {  // padding pair of the batch's last group, or every pixel is done (wave-uniform): w = 0
                         wp[0][i] = wp[1][i] = wp[2][i] = 0u;
                         continue;
                     }
