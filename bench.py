@@ -205,7 +205,9 @@ def main():
                     "algorithmic_bytes": ab[dom], "kernel_ms": round(stages_ms[dom], 4),
                     "whole_view": {"algorithmic_bytes": ab["total"],
                                    "achieved": round(ab["total"] / (ms_per_step * 1e-3) / 1e9, 1),
-                                   "frac": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
+                                   "frac": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   # also against what a float4 copy reaches on this part (6.3 TB/s)
+                                   "frac_of_copy_rate": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / 6300.0, 4)}}
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N == 1 only) ------------------
     cpu_baseline = None
