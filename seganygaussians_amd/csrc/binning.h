@@ -333,6 +333,70 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
     }
 }
 
+// Count pass without enumerating the overlaps: every rect adds +1 / -1 / -1 / +1 at its four corners of a
+// (gy + 1) x (gx + 1) difference grid in LDS (four LDS atomics per Gaussian instead of one per covered tile plus a
+// ten-step owner search), and a 2-D prefix sum of the grid is the number of rects covering each tile -- exactly what
+// the enumeration counts.  Same slices (rank chunks dealt round robin) and the same rects as the emit pass.
+__host__ __device__ inline int count_grid_stride(uint32_t gx) { return (int)((gx + 1) | 1u); }  // odd row stride: column walks spread over the banks
+
+template <bool FULL>
+__global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const BlendRec* __restrict__ rank_rec,
+                                                                uint32_t* __restrict__ partial, uint32_t gx, uint32_t gy)
+{
+    extern __shared__ int s_grid[];  // [(gy + 1) * stride]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stride = count_grid_stride(gx);
+    const int cells = (int)(gy + 1) * stride;
+    for (int c = tid; c < cells; c += BIN_THREADS) s_grid[c] = 0;
+    __syncthreads();
+    const int nwg = (int)gridDim.x;
+    const int rounds = ((P + 63) / 64 + 16 * nwg - 1) / (16 * nwg);
+    for (int it = 0; it < rounds; it++) {
+        const int r = ((it * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
+        if (r >= P) continue;
+        const BlendRec rec = rank_rec[r];
+        const int rad = (int)rec.pm;
+        if (rad <= 0) continue;
+        uint2 rmin, rmax;
+        getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
+        if (!FULL) shrink_rect(rec.xy, rec.co, rad, rmin, rmax);
+        if (rmax.x <= rmin.x || rmax.y <= rmin.y) continue;
+        atomicAdd(&s_grid[rmin.y * stride + rmin.x], 1);
+        atomicAdd(&s_grid[rmin.y * stride + rmax.x], -1);
+        atomicAdd(&s_grid[rmax.y * stride + rmin.x], -1);
+        atomicAdd(&s_grid[rmax.y * stride + rmax.x], 1);
+    }
+    __syncthreads();
+    // prefix along x: one wave per row, 64 cells at a time with a carry
+    for (int y = wave; y < (int)gy; y += BIN_THREADS / 64) {
+        int carry = 0;
+        for (int x0 = 0; x0 < (int)gx; x0 += 64) {
+            const int x = x0 + lane;
+            int v = x < (int)gx ? s_grid[y * stride + x] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(v, o, 64);
+                if (lane >= o) v += t;
+            }
+            v += carry;
+            if (x < (int)gx) s_grid[y * stride + x] = v;
+            carry = __shfl(v, 63, 64);
+        }
+    }
+    __syncthreads();
+    // prefix along y: one thread per column; the running sums are the per-tile counts of this slice
+    uint32_t* my_partial = partial + (size_t)blockIdx.x * (gx * gy);
+    for (int x = tid; x < (int)gx; x += BIN_THREADS) {
+        int run = 0;
+        for (int y = 0; y < (int)gy; y++) {
+            run += s_grid[y * stride + x];
+            s_grid[y * stride + x] = run;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < (int)(gx * gy); t += BIN_THREADS) my_partial[t] = (uint32_t)s_grid[(t / (int)gx) * stride + (t % (int)gx)];
+}
+
 // Per tile: exclusive prefix of partial[slice][tile] over the slices (in place) and tile_total[tile].
 // One workgroup handles 64 tiles x 16 groups of slices; every load is coalesced along the tile axis.
 __global__ void __launch_bounds__(1024) scan_partials_kernel(int ntiles, int nwg, uint32_t* __restrict__ partial,

@@ -311,6 +311,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -356,12 +358,20 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     {
         // count pass over rank slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
         StageTimer t(stream, MI_STAGE_TILE_SCAN);
-        if (full)
-            hipLaunchKernelGGL((bin_ranks_kernel<false, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
-                               img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
+        const size_t cnt_lds = (size_t)(vp.grid_y + 1) * count_grid_stride(vp.grid_x) * sizeof(int);
+        if (g_ablate_fwd & 4096) {  // the enumerating count pass (MI_RAST_ABLATE_FWD=4096: comparisons)
+            if (full)
+                hipLaunchKernelGGL((bin_ranks_kernel<false, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+                                   img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
+            else
+                hipLaunchKernelGGL((bin_ranks_kernel<false, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+                                   img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
+        } else if (full)
+            hipLaunchKernelGGL(bin_count_kernel<true>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
+                               img.tile_count, vp.grid_x, vp.grid_y);
         else
-            hipLaunchKernelGGL((bin_ranks_kernel<false, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
-                               img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
+            hipLaunchKernelGGL(bin_count_kernel<false>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
+                               img.tile_count, vp.grid_x, vp.grid_y);
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)ntiles + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
