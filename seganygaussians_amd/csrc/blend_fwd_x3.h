@@ -14,7 +14,7 @@
 //     The three dropped terms are below 2^-26 of |w f|.  The image is NOT bit-identical to blend_fwd.h (the MFMA rounds
 //     its 16-product partial sums differently from sixteen chained fmaf) but sits at the same f32 rounding level:
 //     max difference between the two kernels 7e-7 of the image scale, RMS error against the fp64-accumulating oracle
-//     2.1e-8 vs 0.7e-8 (tests/test_gpu_parity.py::test_features32_forward_x3_matches_f32_mfma).
+//     2.1e-8 vs 0.7e-8 (tests/test_gpu_parity.py::test_features_forward_x3_matches_f32_mfma).
 //   * per group: 12 MFMA x 32 cycles for 64 px x 32 ch x 16 Gaussians = 24 cycles per (wave, Gaussian) instead of 64.
 // Lane = pixel computes w for all 16 Gaussians of a group, but the MFMA wants lanes 0..31 to hold k = 0..7 and lanes
 // 32..63 k = 8..15 of a 32-pixel block: lane l and lane l ^ 32 exchange half of their packed terms (v_permlane32_swap).

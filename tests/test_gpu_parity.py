@@ -61,12 +61,13 @@ def test_features32_dense():
     assert c["E"] < c["R"], "scene should exercise early termination"
 
 
-def test_features32_forward_x3_matches_f32_mfma(monkeypatch):
-    """The default 32-channel forward accumulates on the bf16 matrix pipe with exactly split operands (blend_fwd_x3.h);
+@pytest.mark.parametrize("C", [32, 64])
+def test_features_forward_x3_matches_f32_mfma(monkeypatch, C):
+    """The default 32 / 64-channel forward accumulates on the bf16 matrix pipe with exactly split operands (blend_fwd_x3.h);
     MI_RAST_ABLATE_FWD=2048 selects the f32-MFMA kernel (a bit-exact fmaf chain).  Same lists, same alpha / T / n_contrib
     (bit-identical), and images that differ by rounding of the f32 accumulation only (a few ulp; same distance from the
     fp64-accumulating oracle)."""
-    inp = hp.make_inputs(60_000, 640, 360, 32, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
+    inp = hp.make_inputs(60_000, 640, 360, C, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
     x3 = hp.GpuRun(inp).forward()
     monkeypatch.setenv("MI_RAST_ABLATE_FWD", "2048")
     f32 = hp.GpuRun(inp).forward()
