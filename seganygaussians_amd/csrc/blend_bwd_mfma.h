@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     const size_t HW = (size_t)H * W;
 
     long long tk[6] = {0, 0, 0, 0, 0, 0};
+    int n_chunks = 0, n_empty = 0, n_pad = 0, n_rows_live = 0;  // profiling counters (ablate & 32)
     const bool prof = (ablate & 32) != 0;
     long long tmark = prof ? clock64() : 0;
 #define TK(i) do { if (prof) { const long long t_ = clock64(); tk[i] += t_ - tmark; tmark = t_; } } while (0)
@@ -411,6 +412,12 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 my_ua[rr * WROW + lane] = u;
             }
             rowmask = __builtin_amdgcn_readfirstlane(rowmask);
+            if (prof) {
+                n_chunks++;
+                n_empty += rowmask == 0 ? 1 : 0;
+                n_pad += max(0, j0 + CHK - cnt);
+                n_rows_live += __builtin_popcount(rowmask);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (rowmask == 0 || (ablate & 2)) continue;
 
@@ -500,7 +507,13 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     }
     TK(4);
     if (prof && lane == 0)
+    {
         for (int i = 0; i < 5; i++) atomicAdd(&gpack[8 * (i + 1) + 6], (float)tk[i]);
+        atomicAdd(&gpack[8 * 6 + 6], (float)n_chunks);
+        atomicAdd(&gpack[8 * 7 + 6], (float)n_empty);
+        atomicAdd(&gpack[8 * 8 + 6], (float)n_pad);
+        atomicAdd(&gpack[8 * 9 + 6], (float)n_rows_live);
+    }
 #undef TK
 }
 

@@ -730,11 +730,13 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
 #undef LAUNCH_BWD_MFMA
     }
     if (g_ablate & 32) {
-        float dbg[48];
+        float dbg[88];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);
         fprintf(stderr, "[mi_rast debug] bwd wave-cycles: head=%.3g dLstage=%.3g recstage=%.3g featstage+select=%.3g chunks+barrierwait=%.3g\n",
                 dbg[14], dbg[22], dbg[30], dbg[38], dbg[46]);
+        fprintf(stderr, "[mi_rast debug] bwd chunks: %.4g of 16 rows, %.4g of them without any contributing pixel; rows: %.4g padding, %.4g with a contributing pixel\n",
+                dbg[54], dbg[62], dbg[70], dbg[78]);
     }
     STAGE_CHECK("render backward");
 
