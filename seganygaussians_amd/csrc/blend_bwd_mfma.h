@@ -1,7 +1,7 @@
-// blend_bwd_mfma.h -- per-tile back-to-front gradient pass for C = 32 / 64 feature channels with f32 MFMA.
+// blend_bwd_mfma.h -- per-tile back-to-front gradient pass for C = 32 / 64 feature channels (and RGB padded to 16) with f32 MFMA.
 //
 // Same mathematics as blend_bwd.h (which restates renderCUDA<C> backward, CF/cuda_rasterizer/backward.cu:399-559,
-// and remains the path for C = 3 / 64 and the mask variants); same tolerance-checked results.  What changes is
+// and remains the path for the mask-only pair and comparisons); same tolerance-checked results.  What changes is
 // where the work runs.  Per valid (wave, Gaussian) pair the VALU version spends ~250 instructions and ~250 LDS
 // cycles, almost all of them in three contractions:
 //     S[g][p]   = sum_ch  f[g][ch]  * dL[p][ch]        (feeds dL/dalpha through the scalar recurrence)
@@ -12,7 +12,7 @@
 // A wave (8x8 pixels) therefore processes its records in chunks of 16 rows:
 //   1. S for 16 rows x 64 pixels: 32 v_mfma_f32_16x16x4_f32 (A = feature rows read from LDS as MFMA operands,
 //      B = dL held in registers), then a transpose through LDS so that lane = pixel again;
-//   2. the short scalar recurrences per pixel (T, R, dL/dalpha: ~35 VALU per row), which leave w and u of the
+//   2. the short scalar recurrences per pixel (T, R, dL/dalpha: ~28 VALU per row), which leave w and u of the
 //      16 rows in LDS, transposed;
 //   3. dF (32 MFMA) and M (16 MFMA) with A = w / u rows from LDS and B = dL (registers) / Phi (generated on the fly);
 //   4. per row ONE 128-byte line of float atomics for dF and ONE 32-byte packed record {mean2D.xy, conic.xyw,
@@ -20,6 +20,7 @@
 // f32 MFMA is an exact fmaf chain (no reduced precision).  Moments are taken about the quadrant centre, so
 // |coordinate| <= 3.5 and recentring to the Gaussian mean is benign (all terms of a sum share their sign pattern
 // with the direct evaluation).
+// Staging (records, feature rows) is per batch of RB2 records; for C = 32 it is pipelined over the batches (BwdCfg::PIPE).
 #pragma once
 
 #include "blend_fwd.h"
