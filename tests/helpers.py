@@ -299,3 +299,90 @@ def compare_gradients(grads: dict, bwd: so.BackwardOut, rtol=RTOL, flip_frac=GRA
         want = np.asarray(want).reshape(got.shape)
         rep[k] = assert_close(k, got, want, rtol=rtol, flip_frac=flip_frac)
     return rep
+
+
+# ---------------------------------------------------------------------------------------------------
+# stricter error statistics (the max-norm floor of assert_close lets small rows hide)
+# ---------------------------------------------------------------------------------------------------
+
+def norm_error(got, want) -> float:
+    """||got - want||_2 / ||want||_2 in fp64."""
+    got = np.asarray(got, np.float64).ravel()
+    want = np.asarray(want, np.float64).ravel()
+    d = float(np.linalg.norm(want))
+    return float(np.linalg.norm(got - want)) / d if d > 0 else float(np.linalg.norm(got))
+
+
+def row_error_report(got, want, rtol=RTOL):
+    """Per-row relative error with a floor at the MEDIAN row magnitude (not the max): row r is bad when
+    ||got_r - want_r||_inf > rtol * (||want_r||_inf + median_r' ||want_r'||_inf over non-zero rows).
+    Returns (fraction of bad rows among non-zero rows, worst ratio err / allowed, median row magnitude,
+    whether a row that is exactly zero in `want` is non-zero in `got`)."""
+    want = np.asarray(want, np.float64)
+    got = np.asarray(got, np.float64).reshape(want.shape)
+    if want.ndim == 1:
+        want, got = want[:, None], got[:, None]
+    want = want.reshape(want.shape[0], -1)
+    got = got.reshape(want.shape)
+    mag = np.abs(want).max(axis=1)
+    nz = mag > 0
+    if not nz.any():
+        return 0.0, 0.0, 0.0, bool((np.abs(got) != 0).any())
+    med = float(np.median(mag[nz]))
+    err = np.abs(got - want).max(axis=1)
+    allowed = rtol * (mag + med)
+    # rows the reference leaves at exactly zero must be exactly zero here too
+    bad = (err > allowed) & nz
+    zero_rows_touched = bool((err[~nz] != 0).any())
+    ratio = float((err[nz] / allowed[nz]).max())
+    return float(bad.sum() / nz.sum()), ratio, med, zero_rows_touched
+
+
+def error_stats(got: dict, want, names=None) -> dict:
+    """{name: {norm, row_frac, row_worst}} for every gradient tensor (want: BackwardOut or dict)."""
+    out = {}
+    for k, g in got.items():
+        w = want[k] if isinstance(want, dict) else getattr(want, k)
+        if w is None or g is None or (names and k not in names):
+            continue
+        w = np.asarray(w).reshape(np.asarray(g).shape)
+        if w.size == 0:
+            continue
+        frac, worst, med, zt = row_error_report(g, w)
+        out[k] = dict(norm=norm_error(g, w), row_frac=frac, row_worst=worst, zero_rows_touched=zt)
+    return out
+
+
+def grads_as_dict(b) -> dict:
+    return {k: v for k, v in b.__dict__.items() if v is not None} if not isinstance(b, dict) else b
+
+
+def compare_forward_outs(a: so.ForwardOut, b: so.ForwardOut, what="", flip_frac=FLIP_FRAC):
+    """Two ForwardOut bundles (CPU oracle and/or oracle/_ref runs): integer path bit-exact, float path <= 1e-4."""
+    sa, sb = a.state, b.state
+    np.testing.assert_array_equal(a.radii, b.radii, err_msg=what + " radii")
+    assert a.num_rendered == b.num_rendered, (what, a.num_rendered, b.num_rendered)
+    np.testing.assert_array_equal(sa.field(so.F_TILES_TOUCHED), sb.field(so.F_TILES_TOUCHED), err_msg=what + " tiles_touched")
+    vis = a.radii > 0
+    np.testing.assert_array_equal(sa.field(so.F_DEPTHS).view(np.uint32)[vis], sb.field(so.F_DEPTHS).view(np.uint32)[vis],
+                                  err_msg=what + " depth bits")
+    np.testing.assert_array_equal(sa.field(so.F_MEANS2D).view(np.uint32).reshape(-1, 2)[vis],
+                                  sb.field(so.F_MEANS2D).view(np.uint32).reshape(-1, 2)[vis], err_msg=what + " means2D bits")
+    np.testing.assert_array_equal(sa.field(so.F_KEYS_SORTED), sb.field(so.F_KEYS_SORTED), err_msg=what + " sorted keys")
+    np.testing.assert_array_equal(sa.field(so.F_POINT_LIST), sb.field(so.F_POINT_LIST), err_msg=what + " point_list")
+    T = len(sb.field(so.F_RANGES)) // 2
+    np.testing.assert_array_equal(sa.field(so.F_RANGES)[:2 * T], sb.field(so.F_RANGES), err_msg=what + " ranges")
+    rep = {}
+    rep["color"] = assert_close(what + " out_color", a.color, b.color, flip_frac=flip_frac)
+    rep["final_T"] = assert_close(what + " final_T", sa.field(so.F_FINAL_T), sb.field(so.F_FINAL_T), flip_frac=flip_frac)
+    rep["n_contrib_mismatch"] = float((sa.field(so.F_N_CONTRIB) != sb.field(so.F_N_CONTRIB)).mean())
+    assert rep["n_contrib_mismatch"] <= max(flip_frac, 1e-4), (what, rep)
+    if a.mask is not None and b.mask is not None:
+        rep["mask"] = assert_close(what + " out_mask", a.mask, b.mask, flip_frac=flip_frac)
+    if a.depth is not None and b.depth is not None:
+        rep["depth"] = assert_close(what + " out_depth", a.depth, b.depth, flip_frac=flip_frac)
+    co_a = sa.field(so.F_CONIC_OPACITY).reshape(-1, 4)[vis]
+    co_b = sb.field(so.F_CONIC_OPACITY).reshape(-1, 4)[vis]
+    rep["conic_bits_equal"] = bool(np.array_equal(co_a.view(np.uint32), co_b.view(np.uint32)))
+    assert_close(what + " conic_opacity", co_a, co_b)
+    return rep
