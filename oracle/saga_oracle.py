@@ -3,7 +3,8 @@
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg.  The product package never imports this module.
 
-PARITY STATUS: "parity unpinned" by the reference's own tests (it ships none).
+PARITY STATUS: pinned against the reference implementation itself (oracle/_ref built by oracle/build_ref.py from the
+reference's sources; tests/test_zz_reference_pin.py, GPU) -- see saga_rast_oracle.h.
 """
 from __future__ import annotations
 

@@ -1,7 +1,7 @@
 /*
  * saga_rast_oracle.c -- CPU restatement of the SAGA / 3DGS differentiable tile rasterizer.
- * TEST INFRASTRUCTURE ONLY (see saga_rast_oracle.h).  PARITY STATUS: "parity unpinned" by the
- * reference's own tests (it has none); pinned by tests/test_oracle_*.py instead.
+ * TEST INFRASTRUCTURE ONLY (see saga_rast_oracle.h).  PARITY STATUS: pinned against the reference
+ * implementation itself (oracle/_ref, tests/test_zz_reference_pin.py) -- details in the header.
  *
  * Citation prefixes: CF/ = submodules/diff-gaussian-rasterization_contrastive_f/,
  * DEPTH/ = submodules/diff-gaussian-rasterization-depth/ (both under /root/reference).

@@ -29,6 +29,8 @@ class Camera:
     viewmatrix: np.ndarray   # (4,4) float32, == world_view_transform (W2C transposed)
     projmatrix: np.ndarray   # (4,4) float32, == full_proj_transform
     campos: np.ndarray       # (3,) float32
+    R: Optional[np.ndarray] = None   # (3,3) camera-to-world rotation and T as scene/cameras.py stores them
+    T: Optional[np.ndarray] = None
 
 
 def projection_matrix(znear: float, zfar: float, fovx: float, fovy: float) -> np.ndarray:
@@ -60,7 +62,8 @@ def look_at_camera(width: int, height: int, focal_px: float, R: Optional[np.ndar
     full = (view_t @ proj_t).astype(np.float32)               # full_proj_transform
     campos = np.linalg.inv(view_t.astype(np.float64))[3, :3].astype(np.float32)
     return Camera(width, height, math.tan(fovx * 0.5), math.tan(fovy * 0.5), view_t,
-                  np.ascontiguousarray(full), campos)
+                  np.ascontiguousarray(full), campos,
+                  np.eye(3) if R is None else np.asarray(R, np.float64), np.zeros(3) if T is None else np.asarray(T, np.float64))
 
 
 def orbit_camera(width: int, height: int, focal_px: float, angle_rad: float, tilt_rad: float = 0.0) -> Camera:

@@ -58,8 +58,10 @@ def build_rotation(q):
 
 def render_dense(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, *,
                  scales=None, rotations=None, cov3D_precomp=None, colors_precomp=None, shs=None, sh_degree=0,
-                 scale_modifier=1.0, means2D_offset=None, mask=None):
-    """All tensor inputs float64.  viewmatrix/projmatrix are the reference's transposed matrices
+                 scale_modifier=1.0, means2D_offset=None, mask=None, helpers=None):
+    """`helpers`: optional tests/reference_helpers.ReferenceHelpers -- SH evaluation, scaling-rotation matrix and the
+    projective transform are then the REFERENCE's own Python functions (imported from /root/reference/utils), not the
+    restatements above.  All tensor inputs float64.  viewmatrix/projmatrix are the reference's transposed matrices
     (row-vector convention: p_hom = [x,y,z,1] @ M).  Returns dict(color (C,H,W), radii, mask, depth,
     n_contrib, final_T)."""
     dt = torch.float64
@@ -70,9 +72,14 @@ def render_dense(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, t
     p_hom = hom @ projmatrix
     p_w = 1.0 / (p_hom[:, 3] + 0.0000001)
     p_proj = p_hom[:, :3] * p_w[:, None]
+    if helpers is not None:
+        p_proj = helpers.geom_transform_points(means3D, projmatrix)      # utils/graphics_utils.py:22-29
     visible = p_view[:, 2] > 0.2
 
-    if cov3D_precomp is None:
+    if cov3D_precomp is None and helpers is not None:
+        L = helpers.build_scaling_rotation(scale_modifier * scales, rotations)   # utils/general_utils.py:101-110
+        Sigma = L @ L.transpose(1, 2)                                            # scene/gaussian_model.py:27-32
+    elif cov3D_precomp is None:
         R = build_rotation(rotations)
         S = torch.diag_embed(scale_modifier * scales)
         L = R @ S
@@ -124,7 +131,8 @@ def render_dense(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, t
     else:
         d = means3D - campos[None]
         d = d / d.norm(dim=1, keepdim=True)
-        colors = torch.clamp_min(eval_sh(sh_degree, shs, d) + 0.5, 0.0)
+        sh_val = eval_sh(sh_degree, shs, d) if helpers is None else helpers.eval_sh(sh_degree, shs, d)
+        colors = torch.clamp_min(sh_val + 0.5, 0.0)
 
     # order: (depth, index) ascending == the (tile|depth) radix sort restricted to any one tile
     depth32 = p_view[:, 2].detach().to(torch.float32)   # keys use fp32 depth bits

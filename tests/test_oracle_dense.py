@@ -146,3 +146,39 @@ def test_mask_depth_variant():
 
 def test_scale_modifier_quirk():
     _run(80, 32, 32, 3, 9, scale_modifier=1.7)
+
+
+def test_dense_ref_helpers_match_reference_python_helpers():
+    """tests/dense_ref.py restates eval_sh / build_rotation / the projective transform so that it can run on the GPU box;
+    where /root/reference exists (the build container) the restatements are checked against the reference's own functions
+    (utils/sh_utils.py:57, utils/general_utils.py:78-110, utils/graphics_utils.py:22-29)."""
+    import torch
+    from tests import dense_ref as dr
+    from tests import reference_helpers as rh
+    if not rh.present():
+        pytest.skip("/root/reference is not on this machine")
+    h = rh.ReferenceHelpers()
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(64, 4, dtype=torch.float64, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    s = torch.rand(64, 3, dtype=torch.float64, generator=g) + 0.1
+    assert torch.allclose(h.build_rotation(q), dr.build_rotation(q), rtol=0, atol=1e-14)
+    L = dr.build_rotation(q) @ torch.diag_embed(s)
+    assert torch.allclose(h.build_scaling_rotation(s, q), L, rtol=0, atol=1e-14)
+    sh = torch.randn(64, 16, 3, dtype=torch.float64, generator=g)
+    d = torch.randn(64, 3, dtype=torch.float64, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    for deg in range(4):
+        assert torch.equal(h.eval_sh(deg, sh, d), dr.eval_sh(deg, sh, d))
+    # matrix conventions: scenes.py cameras == getWorld2View2 / getProjectionMatrix / full_proj (scene/cameras.py:56-65)
+    import math
+    from seganygaussians_amd import scenes
+    for cam in (scenes.look_at_camera(64, 48, 50.0), scenes.orbit_camera(64, 48, 50.0, 0.3, 0.1)):
+        gu = h.graphics_utils
+        fovx, fovy = 2 * math.atan(64 / 100.0), 2 * math.atan(48 / 100.0)
+        proj = gu.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+        view = torch.tensor(gu.getWorld2View2(cam.R, cam.T)).transpose(0, 1)
+        full = view.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0)
+        assert np.allclose(view.numpy(), cam.viewmatrix, rtol=0, atol=1e-6)
+        assert np.allclose(full.numpy(), cam.projmatrix, rtol=0, atol=1e-5)
+        assert np.allclose(view.inverse()[3, :3].numpy(), cam.campos, atol=1e-5)

@@ -184,7 +184,7 @@ def test_product_vs_ref_reduced_cfg3_cfg2_cfg5():
     _product_vs_ref(hp.make_inputs(20_000, 320, 208, 64, seed=5, log_scale=math.log(0.04)))
 
 
-def _check_stats(stats, ref_stats, what):
+def _check_stats(stats, ref_stats, what, row_floor=1e-3):
     """Norm-wise and per-row errors of the product (vs the fp64-accumulating oracle or vs the reference) next to the
     reference's own f32-atomic noise against the same yardstick."""
     for k, s in stats.items():
@@ -193,7 +193,7 @@ def _check_stats(stats, ref_stats, what):
               + (f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}" if r else ""))
         assert not s["zero_rows_touched"], f"{what} {k}: a Gaussian the reference leaves at exactly 0 got a gradient"
         assert s["norm"] <= max(1e-4, 3 * (r["norm"] if r else 0)), (what, k, s, r)
-        assert s["row_frac"] <= max(1e-3, 3 * (r["row_frac"] if r else 0)), (what, k, s, r)
+        assert s["row_frac"] <= max(row_floor, 3 * (r["row_frac"] if r else 0)), (what, k, s, r)
 
 
 def test_full_size_cfg3_product_vs_ref_and_oracle():
@@ -235,4 +235,6 @@ def test_full_size_cfg5_product_vs_ref():
     inp = hp.inputs_from_config("cfg5")
     rep, gpu, ref, rf, rb, grads = _product_vs_ref(inp)
     assert rf.num_rendered > 25_000_000
-    _check_stats(rep["stats"], None, "cfg5 product-vs-ref")
+    # two f32-atomic runs against each other (no fp64 yardstick at this size): the reference's own rows-outside fraction
+    # against the fp64 oracle is 1.2e-3 .. 1.8e-3 for cov3D / scales / rotations on cfg3, so twice that is the floor here
+    _check_stats(rep["stats"], None, "cfg5 product-vs-ref", row_floor=4e-3)
