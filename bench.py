@@ -8,14 +8,23 @@ step   : ONE forward + backward of the rasterizer hot path over one synthetic vi
          drop-in Python API (GaussianRasterizer -> autograd backward), inputs resident in HBM.
          Every allocation, zero-fill and the num_rendered host sync are inside the timed region.
 
-Usage:  python bench.py [--gpus N --steps K --warmup W]
+Usage:  python bench.py [--gpus N --steps K --warmup W] [--config cfg3|cfg5|cfg2|cfg1]
         N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
                 --master-port P bench.py --gpus N --steps K --warmup W
+        cfg2 = BASELINE config 2: 1M Gaussians, 1080p, SH degree 3 RGB + mask + depth, FORWARD only, through the
+        diff_gaussian_rasterization_depth drop-in; cfg5 = 5M Gaussians, 1600x1063, 64-D, fwd+bwd.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) formula) / its
                average duration measured live with HIP events on the launch stream; peak 8000 GB/s.
+               `stages` lists EVERY stage the same way; a stage whose frac exceeds 1 is flagged
+               "algorithm replaced" (the reference's byte count for a pass this pipeline does not perform:
+               never read it as bandwidth).  `whole_view.frac` uses the SURVEY byte count, `whole_view.frac_traffic`
+               the HBM bytes the counters saw (profiles/traffic.json).  `alu` = matrix / vector pipe busy fractions of the
+               dominant kernel from the committed PMC pass (profiles/alu.json): the blend kernels are issue-bound, not HBM-bound.
   cpu_baseline the CPU oracle (kind "port") on this box's host cores, one full view (rank 0, N == 1).
+  parity       that same oracle run compared with the GPU outputs of the benchmarked configuration (product default
+               lists): image and gradients, max-norm criterion of the tests + norm-wise error.
 """
 import argparse
 import json
@@ -31,25 +40,44 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 
 
-def algorithmic_bytes(c, C):
-    """SURVEY.md 8(d) per-stage algorithmic bytes for one view (fp32, C channels)."""
+def algorithmic_bytes(c, C, forward_only=False, sh_coeffs=0, extra=0):
+    """SURVEY.md 8(d) per-stage algorithmic bytes for one view (fp32, C channels; `extra` = mask + depth planes of the
+    DEPTH variant, `sh_coeffs` > 0 adds the SH evaluation of the preprocess pass)."""
     P, V, R, E, L, N, Tn = c["P"], c["V"], c["R"], c["E"], c["L"], c["N"], c["tiles"]
     p = (c["sort_bits"] + 7) // 8
+    Cx = C + extra
     # binning rows keep the REFERENCE algorithm's byte counts (scan / duplicate / 45-bit sort / ranges), mapped
     # onto the stages of our pipeline that replace them (DESIGN.md "Binning")
     st = {
-        "preprocess": 44 * P + 8 * P + 52 * V,
+        "preprocess": 44 * P + 8 * P + 52 * V + ((12 * sh_coeffs + 15) * V if sh_coeffs else 0),
         "tile_scan": 8 * P,
         "emit": 8 * P + 12 * V + 12 * R,
         "tile_sort": (24 * p + 8) * R + 8 * R + 8 * Tn,
         "depth_sort": 0,
-        "blend_fwd": (28 + 4 * C) * E + (4 * C + 8) * N,
-        "blend_bwd": (28 + 4 * C) * L + (4 * C + 8) * N + 2 * 4 * (C + 6) * L,
-        "grad_zero_init": 4 * (24 + C) * P,
-        "geom_bwd": 4 * P * 2 + (88 + 128) * V,
+        "blend_fwd": (28 + 4 * Cx) * E + (4 * Cx + 8) * N,
     }
+    if not forward_only:
+        st.update({
+            "blend_bwd": (28 + 4 * C) * L + (4 * C + 8) * N + 2 * 4 * (C + 6) * L,
+            "grad_zero_init": 4 * (24 + C) * P,
+            "geom_bwd": 4 * P * 2 + (88 + 128) * V,
+        })
     st["total"] = sum(st.values())
     return st
+
+
+def _close(got, want, rtol=1e-4):
+    """(fraction outside |d| <= rtol*|want| + rtol*max|want|, norm-wise error) -- tests/helpers.py's criterion."""
+    import numpy as np
+    got = np.asarray(got, np.float64).ravel()
+    want = np.asarray(want, np.float64).ravel()
+    if want.size == 0:
+        return 0.0, 0.0
+    scale = float(np.abs(want).max())
+    err = np.abs(got - want)
+    frac = float((~(err <= rtol * np.abs(want) + rtol * max(scale, 1e-30))).mean())
+    nrm = float(np.linalg.norm(want))
+    return frac, (float(np.linalg.norm(got - want)) / nrm if nrm > 0 else 0.0)
 
 
 def main():
@@ -57,12 +85,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="cfg3", help="cfg3 (default, headline) | cfg5 | cfg1")
+    ap.add_argument("--config", default="cfg3", help="cfg3 (default, headline) | cfg5 | cfg2 (forward only) | cfg1")
     ap.add_argument("--points", type=int, default=None, help="override Gaussian count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dist-single", action="store_true",
                     help="testing only: initialise torch.distributed (RCCL) with a single rank and run the N > 1 step")
+    ap.add_argument("--ref-on-gpu", action="store_true",
+                    help="reporting only, after the timed region: also time oracle/_ref (the reference's own kernels, translated "
+                         "test-only by oracle/build_ref.py) on the same workload and GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,43 +115,59 @@ def main():
 
     from seganygaussians_amd import _lib, install_dropin, scenes
     install_dropin()
-    from diff_gaussian_rasterization_contrastive_f import GaussianRasterizationSettings
+    from seganygaussians_amd import rasterizer as R
     from seganygaussians_amd.dist import allreduce_grads_async
-    from seganygaussians_amd.rasterizer import make_rasterizer, set_features_ready_event
 
     cfg = scenes.CONFIGS[args.config]
     C, W, H = cfg["C"], cfg["W"], cfg["H"]
     P = cfg["P"] if args.points is None else args.points
-    _, _, GaussianRasterizer = make_rasterizer(C)
-    scene = scenes.make_scene(P, W, H, cfg["focal"], C, cfg["ls_mean"], cfg["ls_std"], seed=0)
+    fwd_only = args.config == "cfg2"      # BASELINE config 2: RGB (SH degree 3) + mask + depth, forward
+    scene = scenes.make_scene(P, W, H, cfg["focal"], C, cfg["ls_mean"], cfg["ls_std"], seed=0, with_shs=fwd_only)
     # one camera per rank: rank 0 is the canonical front view of config 3; other ranks orbit (config 4)
     cam = scenes.look_at_camera(W, H, cfg["focal"]) if rank == 0 else \
         scenes.orbit_camera(W, H, cfg["focal"], 0.05 * rank, 0.02 * rank)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
-    means3D = t(scene.means3D).requires_grad_(True)
-    feats = t(scene.features).requires_grad_(True)
-    opac = t(scene.opacities).requires_grad_(True)
-    scales = t(scene.scales).requires_grad_(True)
-    rots = t(scene.rotations).requires_grad_(True)
+    means3D = t(scene.means3D).requires_grad_(not fwd_only)
+    opac = t(scene.opacities).requires_grad_(not fwd_only)
+    scales = t(scene.scales).requires_grad_(not fwd_only)
+    rots = t(scene.rotations).requires_grad_(not fwd_only)
+    if fwd_only:
+        from diff_gaussian_rasterization_depth import GaussianRasterizationSettings, GaussianRasterizer
+        shs = t(scene.shs)
+        mask = torch.ones(P, device=dev)
+        feats = None
+        leaves = []
+    else:
+        from diff_gaussian_rasterization_contrastive_f import GaussianRasterizationSettings
+        _, _, GaussianRasterizer = R.make_rasterizer(C)
+        feats = t(scene.features).requires_grad_(True)
+        leaves = [means3D, feats, opac, scales, rots]
     settings = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(C, device=dev),
-        scale_modifier=1.0, viewmatrix=t(cam.viewmatrix), projmatrix=t(cam.projmatrix), sh_degree=0,
+        scale_modifier=1.0, viewmatrix=t(cam.viewmatrix), projmatrix=t(cam.projmatrix), sh_degree=3 if fwd_only else 0,
         campos=t(cam.campos), prefiltered=False, debug=False)
     rasterizer = GaussianRasterizer(settings)
     dL = t(scenes.make_grad_image(C, H, W, seed=1))
-    leaves = [means3D, feats, opac, scales, rots]
 
     state = {}
 
     def step():
         for l in leaves:
             l.grad = None
+        if fwd_only:
+            with torch.no_grad():
+                means2D = torch.zeros_like(means3D)
+                color, omask, odepth, radii = rasterizer(means3D=means3D, means2D=means2D, opacities=opac, mask=mask,
+                                                         shs=shs, colors_precomp=None, scales=scales, rotations=rots,
+                                                         cov3D_precomp=None)
+            state.update(radii=radii, color=color, mask=omask, depth=odepth)
+            return
         # config 4: the features of this step are "ready" when the previous step's gradient all-reduce is (in training the
         # optimizer step sits between the two).  Only the blend stage of the forward reads them; the geometry stages of this
         # view -- SAGA trains the feature rows alone, scene/gaussian_model_ff.py:154-162 -- run while the gradients travel.
         ev, _keep = state.pop("pending", (None, None))
         if ev is not None:
-            set_features_ready_event(ev)
+            R.set_features_ready_event(ev)
         means2D = torch.zeros_like(means3D, requires_grad=True)
         color, radii = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=feats, opacities=opac,
                                   scales=scales, rotations=rots, cov3D_precomp=None)
@@ -128,7 +175,7 @@ def main():
         if dist is not None:
             # sum the per-Gaussian feature gradients of the N views over RCCL/xGMI: one flat 128-MB bucket, asynchronous
             state["pending"] = allreduce_grads_async([feats.grad])
-        state["radii"] = radii
+        state.update(radii=radii, color=color.detach(), means2D=means2D)
 
     def barrier():
         ev, _keep = state.pop("pending", (None, None))
@@ -158,6 +205,8 @@ def main():
     stages_ms = {}
     counters = {}
     if rank == 0:
+        if dist is not None:
+            state.pop("pending", None)
         _lib.profile_enable(True)
         acc = {k: 0.0 for k in _lib.MI_STAGES}
         nprof = max(3, min(10, args.steps))
@@ -168,17 +217,16 @@ def main():
             for k in acc:
                 acc[k] += ms[k]
         _lib.profile_enable(False)
-        stages_ms = {k: v / nprof for k, v in acc.items()}
+        stages_ms = {k: v / nprof for k, v in acc.items() if not (fwd_only and k in ("blend_bwd", "geom_bwd"))}
         # counters: one extra (un-timed) native forward whose opaque buffers we can inspect
-        from seganygaussians_amd.rasterizer import rasterize_gaussians_native
         e = torch.empty(0)
         # E and L are counters of the REFERENCE algorithm (positions in its full tile lists): full-list mode for this call
-        prev_mode = _lib.load().mi_rast_set_full_lists(1)
-        with torch.no_grad():
-            num_rendered, _c, _r, _g, _b, imgbuf = rasterize_gaussians_native(
-                C, False, settings.bg, means3D, feats, opac, None, scales, rots, 1.0, e, settings.viewmatrix,
-                settings.projmatrix, cam.tanfovx, cam.tanfovy, H, W, e, 0, settings.campos, False, False)
-        _lib.load().mi_rast_set_full_lists(prev_mode)
+        with torch.no_grad(), R.forward_flags(full_lists=True):
+            res = R.rasterize_gaussians_native(
+                C, fwd_only, settings.bg, means3D, e if fwd_only else feats, opac, mask if fwd_only else None, scales, rots,
+                1.0, e, settings.viewmatrix, settings.projmatrix, cam.tanfovx, cam.tanfovy, H, W,
+                shs if fwd_only else e, 3 if fwd_only else 0, settings.campos, False, False)
+        num_rendered, imgbuf = res[0], res[-1]
         _, ioff = _lib.image_layout(W, H)
         tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
         nc = imgbuf[ioff["n_contrib"]:ioff["n_contrib"] + 4 * W * H].view(torch.int32).reshape(H, W)
@@ -190,61 +238,129 @@ def main():
         V = int((state["radii"] > 0).sum().item())
         counters = dict(P=P, V=V, R=int(num_rendered), E=E, L=L, N=W * H, tiles=tiles_x * tiles_y,
                         sort_bits=32 + int(_lib.load().mi_rast_get_higher_msb(tiles_x * tiles_y)))
-        ab = algorithmic_bytes(counters, C)
+        ab = algorithmic_bytes(counters, C, forward_only=fwd_only, sh_coeffs=16 if fwd_only else 0, extra=2 if fwd_only else 0)
         dom = max((k for k in stages_ms), key=lambda k: stages_ms[k])
         achieved = ab[dom] / (stages_ms[dom] * 1e-3) / 1e9 if stages_ms[dom] > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        # HBM bytes the PMC passes saw (tools/collect_profiles.sh -> profiles/traffic.json); measured on cfg3
+        traffic_all, alu = {}, None
+        if args.config == "cfg3":
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+                traffic_all = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            except Exception:  # noqa: BLE001
+                traffic_all = {}
+            try:
+                alu = json.load(open(os.path.join(ROOT, "profiles", "alu.json"))).get(dom)
+            except Exception:  # noqa: BLE001
+                alu = None
+        tr = lambda k: (traffic_all.get(k) or {}).get("bytes_per_launch")
+        stage_rows = {}
+        for k, ms_k in stages_ms.items():
+            a = ab.get(k, 0)
+            f = a / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_k > 0 else 0.0
+            row = {"ms": round(ms_k, 4), "algorithmic_bytes": a, "frac": round(f, 4), "traffic": tr(k),
+                   "frac_traffic": round(tr(k) / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tr(k) and ms_k > 0 else None}
+            if f > 1.0:
+                row["note"] = "algorithm replaced: the byte count is the reference's pass, which this pipeline does not perform"
+            if a == 0:
+                row["note"] = "no counterpart in the reference's byte table (its 64-bit sort covers the depth order)"
+            stage_rows[k] = row
+        total_traffic = sum(tr(k) for k in stages_ms if tr(k)) if traffic_all else None
+        wv_ach = ab["total"] / (ms_per_step * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": tr(dom),
                     "algorithmic_bytes": ab[dom], "kernel_ms": round(stages_ms[dom], 4),
-                    "whole_view": {"algorithmic_bytes": ab["total"],
-                                   "achieved": round(ab["total"] / (ms_per_step * 1e-3) / 1e9, 1),
-                                   "frac": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "alu": alu, "stages": stage_rows,
+                    "whole_view": {"algorithmic_bytes": ab["total"], "achieved": round(wv_ach, 1),
+                                   "frac": round(wv_ach / HBM_PEAK_GBPS, 4),
                                    # also against what a float4 copy reaches on this part (6.3 TB/s)
-                                   "frac_of_copy_rate": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / 6300.0, 4)}}
+                                   "frac_of_copy_rate": round(wv_ach / 6300.0, 4),
+                                   "traffic": total_traffic,
+                                   "frac_traffic": round(total_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                   if total_traffic else None,
+                                   "note": "frac counts the reference algorithm's bytes (incl. its 45-bit global sort, which "
+                                           "this pipeline replaces); frac_traffic counts the HBM bytes the PMC counters saw"}}
 
-    # ---- CPU baseline: the oracle on this box's host cores (rank 0, N == 1 only) ------------------
+    # ---- CPU baseline: the oracle on this box's host cores (rank 0, N == 1 only) + parity of the benchmarked run ------
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dist_single:
         from oracle import saga_oracle as so
         if args.cpu_threads > 0:
             so.set_num_threads(args.cpu_threads)
         inp = so.Inputs(means3D=scene.means3D, opacities=scene.opacities, viewmatrix=cam.viewmatrix,
                         projmatrix=cam.projmatrix, campos=cam.campos, bg=np.zeros(C, np.float32), image_width=W,
                         image_height=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, channels=C,
-                        colors_precomp=scene.features, scales=scene.scales, rotations=scene.rotations)
+                        colors_precomp=None if fwd_only else scene.features, shs=scene.shs if fwd_only else None,
+                        sh_degree=3 if fwd_only else 0, mask=np.ones(P, np.float32) if fwd_only else None,
+                        scales=scene.scales, rotations=scene.rotations)
         dLn = dL.cpu().numpy()
         c0 = time.perf_counter()
         fo = so.forward(inp)
-        so.backward(inp, fo, dLn)
+        bo = None if fwd_only else so.backward(inp, fo, dLn)
         cpu_s = time.perf_counter() - c0
         cpu_baseline = {"value": round(1.0 / cpu_s, 4), "unit": "views/s", "cores": so.num_threads(), "kind": "port",
-                        "sample": f"1 full view fwd+bwd of {args.config} (P={P}, {W}x{H}, C={C}) in {cpu_s:.2f} s, "
-                                  f"OpenMP over Gaussians/tiles, nproc={os.cpu_count()}"}
+                        "sample": f"1 full view {'fwd' if fwd_only else 'fwd+bwd'} of {args.config} (P={P}, {W}x{H}, C={C}) "
+                                  f"in {cpu_s:.2f} s, OpenMP over Gaussians/tiles, nproc={os.cpu_count()}"}
+        # parity of what was just benchmarked (product default lists) against that oracle run
+        step()
+        torch.cuda.synchronize(dev)
+        pr = {"radii_equal": bool(np.array_equal(state["radii"].cpu().numpy(), fo.radii)), "rtol": 1e-4,
+              "criterion": "|got-want| <= rtol*|want| + rtol*max|want| (tests/helpers.py); norm = ||got-want||2/||want||2"}
+        pairs = [("image", state["color"].cpu().numpy(), fo.color)]
+        if fwd_only:
+            pairs += [("mask", state["mask"].cpu().numpy(), fo.mask), ("depth", state["depth"].cpu().numpy(), fo.depth)]
+        else:
+            pairs += [("dL_dfeatures", feats.grad.cpu().numpy(), bo.dL_dcolors),
+                      ("dL_dmeans3D", means3D.grad.cpu().numpy(), bo.dL_dmeans3D),
+                      ("dL_dmeans2D", state["means2D"].grad.cpu().numpy(), bo.dL_dmeans2D),
+                      ("dL_dopacity", opac.grad.cpu().numpy(), bo.dL_dopacity),
+                      ("dL_dscales", scales.grad.cpu().numpy(), bo.dL_dscales),
+                      ("dL_drotations", rots.grad.cpu().numpy(), bo.dL_drotations)]
+        worst_frac = 0.0
+        for name, got, want in pairs:
+            frac, nrm = _close(got, np.asarray(want).reshape(got.shape))
+            pr[name] = {"frac_outside": float(f"{frac:.3g}"), "norm": float(f"{nrm:.3g}")}
+            worst_frac = max(worst_frac, frac)
+        pr["frac_outside_max"] = float(f"{worst_frac:.3g}")
+        pr["ok"] = bool(pr["radii_equal"] and worst_frac <= 2e-4)
+        parity = pr
+
+    ref_on_gpu = None
+    if rank == 0 and world == 1 and args.ref_on_gpu and not fwd_only:
+        from oracle import saga_oracle as so
+        from oracle import saga_ref as sr
+        inp = so.Inputs(means3D=scene.means3D, opacities=scene.opacities, viewmatrix=cam.viewmatrix,
+                        projmatrix=cam.projmatrix, campos=cam.campos, bg=np.zeros(C, np.float32), image_width=W,
+                        image_height=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, channels=C,
+                        colors_precomp=scene.features, scales=scene.scales, rotations=scene.rotations)
+        ms_ref = sr.RefRun(inp).time_fwd_bwd(dL.cpu().numpy(), steps=5, warmup=2)
+        ref_on_gpu = {"ms_per_view": round(ms_ref, 3), "views_per_s": round(1e3 / ms_ref, 2),
+                      "speedup_of_this_repo": round(ms_ref / ms_per_step, 2),
+                      "what": "oracle/_ref: the reference's own CUDA kernels translated test-only with hipify-perl "
+                              "(-ffp-contract=off), same workload, same GPU, incl. its allocations and zero fills"}
 
     if rank == 0:
+        names = {"cfg3": "train views/sec (fwd+bwd), 1080p, 1M Gaussians, 32-D features",
+                 "cfg2": "forward views/sec, 1080p, 1M Gaussians, SH-3 RGB + mask + depth"}
+        what = (f"BASELINE {args.config}: {P} Gaussians, {W}x{H}, " +
+                ("SH degree 3 RGB + mask + depth, forward only (diff_gaussian_rasterization_depth)" if fwd_only
+                 else f"{C}-D features, fwd+bwd") + ", 1 view/GPU/step" +
+                (", RCCL all-reduce of (P,C) feature grads" if world > 1 else ""))
         out = {
-            "metric": "train views/sec (fwd+bwd), 1080p, 1M Gaussians, 32-D features" if args.config == "cfg3"
-            else f"train views/sec (fwd+bwd), {args.config}",
+            "metric": names.get(args.config, f"train views/sec (fwd+bwd), {args.config}"),
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE {args.config}: {P} Gaussians, {W}x{H}, {C}-D features, fwd+bwd, "
-                                   f"1 view/GPU/step" + (", RCCL all-reduce of (P,C) feature grads" if world > 1 else ""),
-                       "parallelism": f"view-sharded x{world}", "counters": counters,
+            "config": {"workload": what, "parallelism": f"view-sharded x{world}", "counters": counters,
                        "lists": "lean (product default: only overlaps that pass the exact-conservative cull are listed; "
                                 "counters E/L from one full-list call)",
-                       "arithmetic": "f32 throughout; C=32 forward accumulation = exact 3-way bf16 split of f32 operands, "
+                       "arithmetic": "f32 throughout; C=32/64 forward accumulation = exact 3-way bf16 split of f32 operands, "
                                      "six partial products on the bf16 matrix pipe, f32 accumulate (f32 rounding level)",
                        "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()}},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
+        if ref_on_gpu:
+            out["reference_on_gpu"] = ref_on_gpu
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -17,9 +17,14 @@
  *  - `channels` is the reference's compile-time NUM_CHANNELS (config.h:15 = 3,
  *    config_contrastive_f.h:15 = 32); supported: 3, 32, 64 (mi_rast_supported_channels()).
  *  - `mask != NULL` selects the DEPTH variant (adds out_mask/out_depth, dL_dmask).
- *  - `stream` is a hipStream_t (0 = null stream).  The library is stateless between calls; all
- *    memory is owned by the caller; the three opaque buffers have a private layout that is
- *    self-contained given (P, W, H, R) and may be handed back verbatim to the backward call.
+ *  - `stream` is a hipStream_t (0 = null stream).  The rendering entry points are RE-ENTRANT: they keep no
+ *    state between calls (every mode is a per-call argument: `flags`, `features_ready_event`), all memory is
+ *    owned by the caller, and the three opaque buffers have a private layout that is self-contained given
+ *    (P, W, H, R) and may be handed back verbatim to the backward call.  Concurrent calls from different host
+ *    threads, on different streams and on different devices are safe (the only internal resources are a
+ *    pinned word + two events per (host thread, device) for the num_rendered read-back).  The one
+ *    process-level switch is the optional per-stage timing (mi_rast_profile_*), a measurement aid that must
+ *    not be toggled while calls are in flight.
  *  - every function returns 0 on success; on failure a nonzero code, and mi_rast_last_error()
  *    (thread-local) holds the message.  MI_RAST_ERR_NON_RGB carries the reference's text
  *    "For non-RGB, provide precomputed Gaussian colors!" (rasterizer_impl.cu:242-245).
@@ -39,6 +44,11 @@ extern "C" {
 #define MI_RAST_ERR_NON_RGB 2    /* channels != 3 and colors_precomp == NULL          */
 #define MI_RAST_ERR_HIP 3        /* a HIP runtime call or kernel failed               */
 #define MI_RAST_ERR_ALLOC 4      /* a resize callback returned NULL                   */
+
+/* `flags` of mi_rast_forward / mi_rast_mask_forward (0 = product default). */
+#define MI_RAST_FULL_LISTS 1   /* also materialise the reference's point_list and full-list positions (see below) */
+#define MI_RAST_F32_BLEND 2    /* 32/64-channel forward on the f32 FMA-chain kernel instead of the exactly split bf16x3
+                                  matrix kernel (same alpha/T/n_contrib bit for bit; images agree to a few ulp) */
 
 /* Replaces std::function<char*(size_t)> (CF/rasterize_points.cu:27-33): must return a device
  * pointer to at least nbytes bytes (256-B aligned), valid until the caller frees it. */
@@ -76,8 +86,24 @@ int mi_rast_forward(
     float* out_depth,       /* [H, W]  (DEPTH variant) */
     int* radii,             /* [P] */
     int debug,
+    int flags,                    /* MI_RAST_FULL_LISTS | MI_RAST_F32_BLEND; `debug` implies MI_RAST_FULL_LISTS */
+    void* features_ready_event,   /* hipEvent_t or NULL: see "List modes and the features-ready event" below */
     void* stream,
     int* num_rendered /* [host] */);
+
+/* List modes and the features-ready event (both per call).
+ * flags & MI_RAST_FULL_LISTS == 0 (default): "lean" -- only the (Gaussian, tile) overlaps that pass the
+ *    exact-conservative cull are listed and sorted; blend-list positions (and n_contrib, tile_consumed) count blend-list
+ *    records.  Every output of the reference API (images, radii, gradients, num_rendered) is identical to the full mode's.
+ * flags & MI_RAST_FULL_LISTS: "full" -- additionally materialises the reference's point_list
+ *    (CF/cuda_rasterizer/rasterizer_impl.cu:300-317) and full-list positions, so that the integer path can be compared
+ *    bit-exactly with the oracle / the reference.
+ * features_ready_event: training loops in which the geometry is frozen and only colors_precomp (the feature rows) is
+ *    optimised -- SAGA's contrastive feature training, scene/gaussian_model_ff.py:154-162 -- may start a forward before
+ *    the features are final: preprocess, depth order, binning and the per-tile sort read the geometry only.  When not NULL,
+ *    the call makes `stream` wait for this hipEvent_t (recorded by the caller when colors_precomp is ready, e.g. after the
+ *    gradient all-reduce and the optimizer step) right before its blend stage.  The caller keeps the event alive until the
+ *    call returns; the library does not store it. */
 
 /* Replaces CudaRasterizer::Rasterizer::backward (CF/cuda_rasterizer/rasterizer_impl.cu:340-434,
  * declaration rasterizer.h:61-84; DEPTH variant adds dL_dout_mask / dL_dmask).  All dL_d* outputs
@@ -133,7 +159,7 @@ int mi_rast_mask_forward(
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix,
     float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_mask, int* radii, int debug, void* stream, int* num_rendered /* [host] */);
+    float* out_mask, int* radii, int debug, int flags, void* stream, int* num_rendered /* [host] */);
 
 int mi_rast_mask_backward(
     int P, int R, int width, int height,
@@ -148,21 +174,6 @@ const char* mi_rast_version(void);
 int mi_rast_supported_channels(int* out, int n);
 /* Reference helper getHigherMsb (CF/cuda_rasterizer/rasterizer_impl.cu:35-50), host side. */
 uint32_t mi_rast_get_higher_msb(uint32_t n);
-/* List mode of the forward passes (process-wide; returns the previous value).
- * 0 (default): "lean" -- only the (Gaussian, tile) overlaps that pass the exact-conservative cull are listed and
- *    sorted; blend-list positions (and n_contrib, tile_consumed) count blend-list records.  Every output of the
- *    reference API (images, radii, gradients, num_rendered) is identical to the full mode's.
- * 1: "full" -- additionally materialises the reference's point_list (CF/cuda_rasterizer/rasterizer_impl.cu:300-317)
- *    and full-list positions, so that the integer path can be compared bit-exactly with the oracle.  The reference's
- *    `debug` flag implies it for that call. */
-int mi_rast_set_full_lists(int on);
-/* Training loops in which the geometry is frozen and only colors_precomp (the feature rows) is optimised -- SAGA's
- * contrastive feature training, scene/gaussian_model_ff.py:154-162 -- may start the next forward before the features are
- * final: preprocess, depth order, binning and the per-tile sort read the geometry only.  The NEXT mi_rast_forward call
- * makes its stream wait for `hip_event` (a hipEvent_t recorded when colors_precomp is ready, e.g. after the gradient
- * all-reduce and the optimizer step) right before its blend stage, then forgets the event.  NULL cancels. */
-int mi_rast_set_features_ready_event(void* hip_event);
-
 /* Private-layout maps of the three opaque buffers, so tests can compare the integer path
  * bit-exactly with the oracle.  Each call fills `offsets` (bytes from the buffer start) for the
  * fields listed, and returns the total size in bytes. */
@@ -177,8 +188,9 @@ size_t mi_rast_image_layout(int width, int height, size_t* offsets /* [MI_IMG_NF
 size_t mi_rast_binning_layout(int R, size_t* offsets /* [MI_BIN_NFIELDS] */);
 
 /* Per-stage HIP-event timing on the caller's stream (bench.py's live roofline measurement).
- * When enabled, forward/backward record events between stages; mi_rast_profile_read synchronises
- * the last call's events and returns elapsed milliseconds per stage. */
+ * When enabled (process-wide switch; toggle it only while no call is in flight), forward/backward record
+ * events between stages (one event set per device); mi_rast_profile_read synchronises the current device's
+ * events of the last call and returns elapsed milliseconds per stage. */
 enum { MI_STAGE_PREPROCESS = 0, MI_STAGE_DEPTH_SORT, MI_STAGE_TILE_SCAN, MI_STAGE_EMIT, MI_STAGE_TILE_SORT,
        MI_STAGE_BLEND_FWD, MI_STAGE_BLEND_BWD, MI_STAGE_GEOM_BWD, MI_STAGE_COUNT };
 int mi_rast_profile_enable(int on);

@@ -13,13 +13,14 @@ MI_GEOM_FIELDS = ["depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped
                   "depth_key", "index_rec", "sorted_idx", "sort_temp", "bwd_pack", "rank_rec"]
 MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed", "tile_count", "tile_cursor", "num_rendered", "blend_count", "tile_nsurv"]
 MI_BIN_FIELDS = ["entries", "scratch", "point_list", "blend_rec"]
+MI_RAST_FULL_LISTS, MI_RAST_F32_BLEND = 1, 2   # `flags` of mi_rast_forward (include/mi_rast.h)
 MI_STAGES = ["preprocess", "depth_sort", "tile_scan", "emit", "tile_sort", "blend_fwd", "blend_bwd", "geom_bwd"]
 
 EXPORTS = [
     "mi_rast_forward", "mi_rast_backward", "mi_rast_mark_visible", "mi_rast_mask_forward",
     "mi_rast_mask_backward", "mi_rast_last_error", "mi_rast_version", "mi_rast_supported_channels",
     "mi_rast_get_higher_msb", "mi_rast_geometry_layout", "mi_rast_image_layout", "mi_rast_binning_layout",
-    "mi_rast_profile_enable", "mi_rast_profile_read", "mi_rast_set_full_lists", "mi_rast_set_features_ready_event",
+    "mi_rast_profile_enable", "mi_rast_profile_read",
     "mi_knn_smooth_forward", "mi_knn_smooth_backward",  # include/mi_knn_smooth.h
 ]
 
@@ -38,19 +39,20 @@ def load():
     # PyTorch-ROCm ships its own HIP runtime; load it first so that this library binds to the same one (loading
     # /opt/rocm's copy first leaves the process with a runtime that sees no device once torch initialises its own)
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get("MI_RAST_LIB") or LIB_PATH   # MI_RAST_LIB: e.g. the profiling build (build.py), for tools/
+    if not os.path.exists(lib_path):
         raise MiRastError(
-            f"HIP extension {LIB_PATH} is missing. Build it with `python -m seganygaussians_amd.build` "
+            f"HIP extension {lib_path} is missing. Build it with `python -m seganygaussians_amd.build` "
             "(or __graft_entry__.build()). There is no CPU fallback.")
     try:
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(lib_path)
     except OSError as e:  # e.g. libamdhip64 missing
-        raise MiRastError(f"cannot load {LIB_PATH}: {e}") from e
+        raise MiRastError(f"cannot load {lib_path}: {e}") from e
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     L.mi_rast_forward.restype = i
     L.mi_rast_forward.argtypes = [RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, i, i, i, i, vp, i, i,
                                   vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, i,
-                                  vp, vp, vp, vp, vp, i, vp, C.POINTER(i)]
+                                  vp, vp, vp, vp, vp, i, i, vp, vp, C.POINTER(i)]
     L.mi_rast_backward.restype = i
     L.mi_rast_backward.argtypes = [i, i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
@@ -58,7 +60,7 @@ def load():
     L.mi_rast_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
     L.mi_rast_mask_forward.restype = i
     L.mi_rast_mask_forward.argtypes = [RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, i, i, i, vp, vp, vp, vp, f,
-                                       vp, vp, vp, vp, f, f, i, vp, vp, i, vp, C.POINTER(i)]
+                                       vp, vp, vp, vp, f, f, i, vp, vp, i, i, vp, C.POINTER(i)]
     L.mi_rast_mask_backward.restype = i
     L.mi_rast_mask_backward.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, i, vp]
     L.mi_rast_last_error.restype = C.c_char_p
@@ -75,10 +77,6 @@ def load():
     L.mi_rast_image_layout.argtypes = [i, i, C.POINTER(C.c_size_t)]
     L.mi_rast_profile_enable.restype = i
     L.mi_rast_profile_enable.argtypes = [i]
-    L.mi_rast_set_full_lists.restype = i
-    L.mi_rast_set_full_lists.argtypes = [i]
-    L.mi_rast_set_features_ready_event.restype = i
-    L.mi_rast_set_features_ready_event.argtypes = [vp]
     L.mi_rast_profile_read.restype = i
     L.mi_rast_profile_read.argtypes = [C.POINTER(f)]
     u32 = C.c_uint32

@@ -47,5 +47,25 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+PROF_LIB_PATH = os.path.join(_HERE, "libmi_rast_prof.so")
+
+
+def build_profiling_library(verbose: bool = False) -> str:
+    """The same sources with -DMI_RAST_PROFILING: run-time ablation masks (MI_RAST_ABLATE / MI_RAST_ABLATE_FWD), in-kernel
+    cycle counters, the VALU comparison kernels.  For tools/ only; the product library carries none of it.  Select it with
+    MI_RAST_LIB=<path> (seganygaussians_amd/_lib.py)."""
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-DMI_RAST_PROFILING", "-o", PROF_LIB_PATH + ".tmp",
+                                          os.path.join(SRC_DIR, "mi_rast.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(PROF_LIB_PATH + ".tmp", PROF_LIB_PATH)
+    return PROF_LIB_PATH
+
+
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    if "--profiling" in sys.argv:
+        print(build_profiling_library(verbose=True))
+    else:
+        print(build_library(force=True, verbose=True))

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     auto flush = [&]() {
         // LDS rows written by this wave's own lanes: wave-local, no workgroup barrier needed
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const int n = (ablate & 2) ? 0 : __builtin_amdgcn_readfirstlane(nslots);
+        const int n = MI_ABLATE(2) ? 0 : __builtin_amdgcn_readfirstlane(nslots);
         if constexpr (WIDE) {
             float sum[SLOTS];
 #pragma unroll
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     };
     // quad-reduce a per-pixel value and park the 16 partials of field `fi` of the current slot
     auto park = [&](int fi, float v) {
-        if (ablate & 4) return;
+        if MI_ABLATE(4) return;
         v += dpp_mov<0xB1>(v);
         v += dpp_mov<0x4E>(v);
         const int n = __builtin_amdgcn_readfirstlane(nslots);
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         // ---- B: features of this batch; clear the tile accumulators
         if constexpr (WIDE) {
             constexpr int F4 = C / 4;
-            if (!(ablate & 32))
+            if (!MI_ABLATE(32))
 #pragma unroll
             for (int k = 0; k < ROWS * F4 / BATCH; k++) {
                 const int q = tid + BATCH * k;
@@ -256,14 +256,14 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 npm = s_pm[rn];
                 const int pos = (int)(pm >> 4);  // 0-based forward position in the tile list
                 if (!((pm >> wave) & 1u) || pos >= wave_Lt) continue;
-                if (ablate & 64) continue;
+                if MI_ABLATE(64) continue;
                 const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
                 const float power = -0.5f * (cco.x * dx * dx + cco.z * dy * dy) - cco.y * dx * dy;
                 const float G = __expf(power);
                 const float alpha = fminf(0.99f, cco.w * G);
                 const bool valid = (pos < last_contributor) && power <= 0.0f && alpha >= (1.0f / 255.0f);
                 if (ballot64(valid) == 0) continue;
-                if (ablate & 16) continue;
+                if MI_ABLATE(16) continue;
 
                 const float one_m_alpha_inv = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = valid ? T * one_m_alpha_inv : T;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                     park(6, w * dL_dout_mask_i);
                 } else {
                     float S0 = 0.f, S1 = 0.f;
-                    if (!(ablate & 8))
+                    if (!MI_ABLATE(8))
 #pragma unroll
                     for (int ch = 0; ch < C; ch += 2) {
                         S0 = fmaf(s_feat[r * ROW + ch], dL_dpixel[ch], S0);
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
             flush();
         }
         __syncthreads();
-        if (ablate & 1) continue;
+        if MI_ABLATE(1) continue;
 
         // ---- D: one HBM atomic per touched (tile, Gaussian): C channels (128 B at C=32) + one packed 32-B record
         if constexpr (C > 0 && !WIDE) {

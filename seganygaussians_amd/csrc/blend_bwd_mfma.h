@@ -101,8 +101,8 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
     const size_t HW = (size_t)H * W;
 
     long long tk[6] = {0, 0, 0, 0, 0, 0};
-    int n_chunks = 0, n_empty = 0, n_pad = 0, n_rows_live = 0;  // profiling counters (ablate & 32)
-    const bool prof = (ablate & 32) != 0;
+    int n_chunks = 0, n_empty = 0, n_pad = 0, n_rows_live = 0;  // profiling counters (MI_ABLATE(32), profiling build only)
+    const bool prof = MI_ABLATE(32);
     long long tmark = prof ? clock64() : 0;
 #define TK(i) do { if (prof) { const long long t_ = clock64(); tk[i] += t_ - tmark; tmark = t_; } } while (0)
     // Everything the tile needs from memory is requested up front (tile header, per-pixel state, the gradient
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
             for (int k = 0; k < NK; k++) {
                 const int e = tid + BATCH * k;
                 const int g = e / F4, part = e % F4;
-                if (g < nr && !(ablate & 4)) s_feat4[g * (FROW / 4) + part] = v[k];
+                if (g < nr && !MI_ABLATE(4)) s_feat4[g * (FROW / 4) + part] = v[k];
             }
         }
         // The next batch's records are requested only now: vmcnt retires in order, so a request issued before the
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
         cnt = __builtin_amdgcn_readfirstlane(cnt);
         if (lane < CHK) s_list[wave][cnt + lane] = (uint32_t)(RB2 * sizeof(BwdPar));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (ablate & 1) cnt = 0;
+        if MI_ABLATE(1) cnt = 0;
         TK(3);
         for (int j0 = 0; j0 < cnt; j0 += CHK) {
             // ---- 1. S = F . dL^T  (16 rows x 64 pixels, K = 32 channels); lane (n16, kq) feeds row n16
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 n_rows_live += __builtin_popcount(rowmask);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (rowmask == 0 || (ablate & 2)) continue;
+            if (rowmask == 0 || MI_ABLATE(2)) continue;
 
             // ---- 3. dF = W^T . dL  and  M = U^T . Phi   (A rows from LDS, lane (m = n16, kq) reads pixels 16kq..16kq+15)
             v4f facc[NB];
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 const int row = 4 * kq + r;
                 const bool act = (rowmask >> row) & 1u;
                 const uint32_t gid = (uint32_t)__shfl(my_gid, row, 64);
-                if (act && !(ablate & 64)) {
+                if (act && !MI_ABLATE(64)) {
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
                         const int ch = 16 * nb + n16;
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 for (int it = 0; it < 2; it++) {
                     const int row2 = 8 * it + (lane >> 3), f = lane & 7;
                     const uint32_t gid2 = (uint32_t)__shfl(my_gid, row2, 64);
-                    if (((rowmask >> row2) & 1u) && f < 6 && !(ablate & 128)) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * 8 + f]);
+                    if (((rowmask >> row2) & 1u) && f < 6 && !MI_ABLATE(128)) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * 8 + f]);
                 }
             }
         }

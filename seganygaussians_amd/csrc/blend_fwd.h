@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
             constexpr int F4 = C / 4;  // float4s per Gaussian
             // All the loads are issued before the first LDS write (unconditionally: a clamped row index keeps the
             // address valid) -- written as one guarded load-then-store per k, hipcc emits a full vmcnt(0) round trip per k.
-            if (!(ablate & 4)) {
+            if (!MI_ABLATE(4)) {
                 constexpr int NK = FB * F4 / BATCH;
                 float4 v[NK];
 #pragma unroll

@@ -11,6 +11,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing experiments (pieces of a kernel switched off by a run-time bit mask; results become wrong) exist only in the
+// profiling build (-DMI_RAST_PROFILING -> libmi_rast_prof.so).  In the product build MI_ABLATE(bit) is the constant
+// `false`, so the kernels carry no dead branches and the `ablate` argument is unused.
+#ifdef MI_RAST_PROFILING
+#define MI_ABLATE(bit) (((ablate) & (bit)) != 0)
+#else
+#define MI_ABLATE(bit) (false)
+#endif
+
 namespace mirast {
 
 constexpr int R_SLOTS = 64;        // partial sums of R, one per 128-byte line

@@ -6,9 +6,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "binning.h"
@@ -112,7 +114,8 @@ DepthScratch depth_scratch(char* base, int P)
     return d;
 }
 
-// ---- host-side scratch for the num_rendered read-back: pinned word + event, one per host thread -------
+// ---- host-side scratch for the num_rendered read-back: pinned words + two events per (host thread, device) ----
+constexpr int MAX_DEVICES = 64;
 struct HostSync {
     int* pinned = nullptr;   // R partial sums, then {R, longest tile list} of the range scan
     hipEvent_t ev = nullptr;
@@ -128,26 +131,57 @@ struct HostSync {
         return true;
     }
 };
-thread_local HostSync g_host_sync;
+thread_local HostSync g_host_sync_tl[MAX_DEVICES];
+
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return -1;
+    return dev;
+}
 
 // ---- per-stage profiling (bench.py) -----------------------------------------------------------
-bool g_profile = false;
-hipEvent_t g_ev[MI_STAGE_COUNT][2];
-bool g_ev_created = false;
-bool g_ev_used[MI_STAGE_COUNT];
+// A measurement aid, not part of the rendering state: one process-wide switch, one event set per device (created on
+// first use on that device).  Toggle only while no call is in flight (include/mi_rast.h).
+std::atomic<bool> g_profile{false};
+struct ProfileEvents {
+    hipEvent_t ev[MI_STAGE_COUNT][2];
+    bool created = false;
+    bool used[MI_STAGE_COUNT] = {};
+};
+ProfileEvents g_prof[MAX_DEVICES];
+std::mutex g_prof_mutex;
+
+ProfileEvents* profile_events(int dev)
+{
+    if (dev < 0) return nullptr;
+    ProfileEvents& pe = g_prof[dev];
+    if (!pe.created) {
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (!pe.created) {
+            for (int i = 0; i < MI_STAGE_COUNT; i++)
+                for (int k = 0; k < 2; k++)
+                    if (hipEventCreate(&pe.ev[i][k]) != hipSuccess) return nullptr;
+            pe.created = true;
+        }
+    }
+    return &pe;
+}
 
 struct StageTimer {
     hipStream_t s;
     int stage;
-    StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_)
+    ProfileEvents* pe;
+    StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_), pe(nullptr)
     {
-        if (g_profile) (void)hipEventRecord(g_ev[stage][0], s);
+        if (g_profile.load(std::memory_order_relaxed)) pe = profile_events(current_device());
+        if (pe) (void)hipEventRecord(pe->ev[stage][0], s);
     }
     ~StageTimer()
     {
-        if (g_profile) {
-            (void)hipEventRecord(g_ev[stage][1], s);
-            g_ev_used[stage] = true;
+        if (pe) {
+            (void)hipEventRecord(pe->ev[stage][1], s);
+            pe->used[stage] = true;
         }
     }
 };
@@ -253,11 +287,22 @@ BinPtrs bin_from(char* base, int R)
     return b;
 }
 
-// Timing experiments only: MI_RAST_ABLATE=<bitmask> disables pieces of the backward blend (results become wrong).
-int g_ablate = 0;
-int g_full_lists = 0;  // mi_rast_set_full_lists
-hipEvent_t g_features_ready = nullptr;  // mi_rast_set_features_ready_event (one-shot)
-int g_ablate_fwd = 0;
+// Timing experiments exist only in the profiling build (-DMI_RAST_PROFILING, seganygaussians_amd/build.py:
+// libmi_rast_prof.so): MI_RAST_ABLATE / MI_RAST_ABLATE_FWD=<bitmask> disable pieces of the blend kernels (results become
+// wrong).  The product build compiles none of it: no getenv, no run-time switches inside the kernels (common.h: MI_ABLATE).
+#ifdef MI_RAST_PROFILING
+int ablate_env(const char* name)
+{
+    const char* ab = getenv(name);
+    return ab ? atoi(ab) : 0;
+}
+#else
+constexpr int ablate_env(const char*) { return 0; }
+#endif
+
+// One-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup), per device.
+std::atomic<bool> g_attr_set[MAX_DEVICES];
+std::mutex g_attr_mutex;
 
 bool channels_supported(int c) { return c == 3 || c == 32 || c == 64; }
 
@@ -267,8 +312,13 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                          int W, int H, const float* means3D, const float* shs, int colors_given,
                          const float* opacities, const float* scales, const float* rotations,
                          const float* cov3D_precomp, const ViewParams& vp, int prefiltered, int* radii, int debug,
-                         hipStream_t stream, GeomPtrs& geom, ImgPtrs& img, BinPtrs& bin, int* num_rendered)
+                         int flags, hipStream_t stream, GeomPtrs& geom, ImgPtrs& img, BinPtrs& bin, int* num_rendered)
 {
+    const int dev = current_device();
+    if (dev < 0) return fail(MI_RAST_ERR_HIP, "hipGetDevice failed (or device ordinal >= 64)");
+    HostSync& g_host_sync = g_host_sync_tl[dev];
+    const int g_ablate_fwd = ablate_env("MI_RAST_ABLATE_FWD");
+    (void)g_ablate_fwd;
     size_t goff[MI_GEOM_NFIELDS], ioff[MI_IMG_NFIELDS];
     const size_t geom_size = mi_rast_geometry_layout(P, goff);
     char* geom_base = geometry_buffer(geom_size, geometry_user);
@@ -303,9 +353,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         if (culled)
             return fail(MI_RAST_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");
     }
-    {
-        static bool attr_set = false;  // one-time opt-in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
-        if (!attr_set) {
+    if (!g_attr_set[dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lock(g_attr_mutex);
+        if (!g_attr_set[dev].load(std::memory_order_relaxed)) {
             const int max_lds = (int)((BIN_MAX_TILES + 11 * 1024 + 16) * sizeof(uint32_t));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -319,7 +369,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                                         DS_NBK * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         DS_NBK * (int)sizeof(uint32_t)));
-            attr_set = true;
+            g_attr_set[dev].store(true, std::memory_order_release);
         }
     }
     // R is known after the preprocess pass; its copy to the host overlaps the depth sort and the counting passes.
@@ -351,14 +401,15 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     }
     STAGE_CHECK("depth sort");
     // Full lists (the reference's point_list and full-list positions) are materialised on request -- the reference's
-    // `debug` flag or mi_rast_set_full_lists(1) -- ; otherwise only the overlaps that pass the cull are listed.
-    const bool full = debug != 0 || g_full_lists != 0;
+    // `debug` flag or MI_RAST_FULL_LISTS -- ; otherwise only the overlaps that pass the cull are listed.
+    const bool full = debug != 0 || (flags & MI_RAST_FULL_LISTS) != 0;
     const int nwg = bin_workgroups(P);
     const size_t bin_lds = ((size_t)((ntiles + 3) & ~3) + 3 * 1024 + 16) * sizeof(uint32_t);
     {
         // count pass over rank slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
         StageTimer t(stream, MI_STAGE_TILE_SCAN);
         const size_t cnt_lds = (size_t)(vp.grid_y + 1) * count_grid_stride(vp.grid_x) * sizeof(int);
+#ifdef MI_RAST_PROFILING
         if (g_ablate_fwd & 4096) {  // the enumerating count pass (MI_RAST_ABLATE_FWD=4096: comparisons)
             if (full)
                 hipLaunchKernelGGL((bin_ranks_kernel<false, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
@@ -366,7 +417,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             else
                 hipLaunchKernelGGL((bin_ranks_kernel<false, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
                                    img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
-        } else if (full)
+        } else
+#endif
+        if (full)
             hipLaunchKernelGGL(bin_count_kernel<true>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
                                img.tile_count, vp.grid_x, vp.grid_y);
         else
@@ -411,7 +464,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         int rank_bits = 1;
         while ((1ll << rank_bits) < (long long)P) rank_bits++;
         int passes = (rank_bits + 7) / 8;
+#ifdef MI_RAST_PROFILING
         if (g_ablate_fwd & 256) passes = 0;  // timing experiment: skip the radix passes (wrong order)
+#endif
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
             // three list-length classes (256 threads + 20 KB of LDS, 1024 threads + 64 KB, 1024 threads + 112 KB); a class is launched only if
@@ -451,6 +506,7 @@ void launch_blend_fwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& i
                       const GeomPtrs& geom, const float* features, const float* mask, const float* bg,
                       float* out_color, float* out_mask, float* out_depth)
 {
+    const int g_ablate_fwd = ablate_env("MI_RAST_ABLATE_FWD");
     hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
                        bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
                        img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, g_ablate_fwd);
@@ -461,6 +517,7 @@ void launch_blend_bwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& i
                       const GeomPtrs& geom, const float* colors, const float* bg, const float* dL_dpix,
                       const float* dL_dout_mask, float* dL_dcolor)
 {
+    const int g_ablate = ablate_env("MI_RAST_ABLATE");
     hipLaunchKernelGGL((blend_bwd_kernel<C, MASKGRAD>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
                        bin.blend_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
                        dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate);
@@ -471,7 +528,7 @@ void launch_blend_bwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& i
 extern "C" {
 
 const char* mi_rast_last_error(void) { return g_last_error.c_str(); }
-const char* mi_rast_version(void) { return "mi_rast 0.1 (gfx950)"; }
+const char* mi_rast_version(void) { return "mi_rast 0.2 (gfx950)"; }
 
 int mi_rast_supported_channels(int* out, int n)
 {
@@ -525,19 +582,6 @@ int mi_knn_smooth_backward(int P, int C, int K, const int* knn_idx, const int* i
 }
 
 // CF/cuda_rasterizer/rasterizer_impl.cu:35-50
-int mi_rast_set_features_ready_event(void* hip_event)
-{
-    g_features_ready = (hipEvent_t)hip_event;
-    return MI_RAST_OK;
-}
-
-int mi_rast_set_full_lists(int on)
-{
-    const int prev = g_full_lists;
-    g_full_lists = on ? 1 : 0;
-    return prev;
-}
-
 uint32_t mi_rast_get_higher_msb(uint32_t n)
 {
     uint32_t msb = sizeof(n) * 4;
@@ -600,26 +644,24 @@ size_t mi_rast_binning_layout(int R, size_t* off)
 
 int mi_rast_profile_enable(int on)
 {
-    if (on && !g_ev_created) {
-        for (int i = 0; i < MI_STAGE_COUNT; i++)
-            for (int k = 0; k < 2; k++)
-                if (hipEventCreate(&g_ev[i][k]) != hipSuccess) return fail(MI_RAST_ERR_HIP, "hipEventCreate failed");
-        g_ev_created = true;
-    }
-    g_profile = on != 0;
-    for (int i = 0; i < MI_STAGE_COUNT; i++) g_ev_used[i] = false;
+    if (on && !profile_events(current_device())) return fail(MI_RAST_ERR_HIP, "hipEventCreate failed");
+    g_profile.store(on != 0);
+    for (int d = 0; d < MAX_DEVICES; d++)
+        for (int i = 0; i < MI_STAGE_COUNT; i++) g_prof[d].used[i] = false;
     return MI_RAST_OK;
 }
 
 int mi_rast_profile_read(float* ms)
 {
+    const int dev = current_device();
+    ProfileEvents* pe = dev >= 0 && g_prof[dev].created ? &g_prof[dev] : nullptr;
     for (int i = 0; i < MI_STAGE_COUNT; i++) {
         ms[i] = 0.f;
-        if (g_ev_created && g_ev_used[i]) {
-            HIP_TRY(hipEventSynchronize(g_ev[i][1]));
-            HIP_TRY(hipEventElapsedTime(&ms[i], g_ev[i][0], g_ev[i][1]));
+        if (pe && pe->used[i]) {
+            HIP_TRY(hipEventSynchronize(pe->ev[i][1]));
+            HIP_TRY(hipEventElapsedTime(&ms[i], pe->ev[i][0], pe->ev[i][1]));
+            pe->used[i] = false;
         }
-        g_ev_used[i] = false;
     }
     return MI_RAST_OK;
 }
@@ -631,14 +673,10 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
                     float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                     const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
                     const float* mask, float* out_color, float* out_mask, float* out_depth, int* radii, int debug,
-                    void* stream_, int* num_rendered)
+                    int flags, void* features_ready_event, void* stream_, int* num_rendered)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (num_rendered) *num_rendered = 0;
-    {
-        const char* ab = getenv("MI_RAST_ABLATE_FWD");
-        g_ablate_fwd = ab ? atoi(ab) : 0;
-    }
     if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
     if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
     if (mask && channels != 3) return fail(MI_RAST_ERR_INVALID, "mask/depth variant is built for 3 channels");
@@ -655,22 +693,20 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
     BinPtrs bin;
     rc = geometry_and_binning(geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P,
                               D, M, width, height, means3D, shs, colors_precomp != nullptr, opacities, scales,
-                              rotations, cov3D_precomp, vp, prefiltered, radii, debug, stream, geom, img, bin,
+                              rotations, cov3D_precomp, vp, prefiltered, radii, debug, flags, stream, geom, img, bin,
                               num_rendered);
     if (rc) return rc;
 
     const float* feature_ptr = colors_precomp != nullptr ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:321
-    if (g_features_ready != nullptr) {
+    if (features_ready_event != nullptr) {
         // everything above depends on the geometry only; colors_precomp may still be in the making (mi_rast.h)
-        const hipEvent_t ev = g_features_ready;
-        g_features_ready = nullptr;
-        HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+        HIP_TRY(hipStreamWaitEvent(stream, (hipEvent_t)features_ready_event, 0));
     }
     {
         StageTimer t(stream, MI_STAGE_BLEND_FWD);
         if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth);
         else if (channels == 3) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
-        else if (g_ablate_fwd & 2048) {  // f32-MFMA forward (MI_RAST_ABLATE_FWD=2048: comparisons)
+        else if (flags & MI_RAST_F32_BLEND) {  // f32 FMA-chain forward (include/mi_rast.h)
             if (channels == 32) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
             else launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
         } else if (channels == 32)
@@ -697,10 +733,8 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (P <= 0) return MI_RAST_OK;
-    {
-        const char* ab = getenv("MI_RAST_ABLATE");
-        g_ablate = ab ? atoi(ab) : 0;
-    }
+    const int g_ablate = ablate_env("MI_RAST_ABLATE");
+    (void)g_ablate;
     if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
     const bool maskgrad = dL_dmask != nullptr;
     if (maskgrad && (channels != 3 || !dL_dout_mask)) return fail(MI_RAST_ERR_INVALID, "mask gradient needs 3 channels and dL_dout_mask");
@@ -718,17 +752,21 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     hipLaunchKernelGGL((blend_bwd_mfma_kernel<__VA_ARGS__>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,    \
                        bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib, dL_dpix, \
                        dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
+#ifdef MI_RAST_PROFILING
         if (g_ablate & 1024) {  // the VALU kernels (timing comparisons)
             if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor);
             else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
             else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
             else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
-        } else if (maskgrad) LAUNCH_BWD_MFMA(16, 3, true);
+        } else
+#endif
+        if (maskgrad) LAUNCH_BWD_MFMA(16, 3, true);
         else if (channels == 3) LAUNCH_BWD_MFMA(16, 3, false);
         else if (channels == 32) LAUNCH_BWD_MFMA(32);
         else LAUNCH_BWD_MFMA(64);
 #undef LAUNCH_BWD_MFMA
     }
+#ifdef MI_RAST_PROFILING
     if (g_ablate & 32) {
         float dbg[88];
         (void)hipStreamSynchronize(stream);
@@ -738,6 +776,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         fprintf(stderr, "[mi_rast debug] bwd chunks: %.4g of 16 rows, %.4g of them without any contributing pixel; rows: %.4g padding, %.4g with a contributing pixel\n",
                 dbg[54], dbg[62], dbg[70], dbg[78]);
     }
+#endif
     STAGE_CHECK("render backward");
 
     const float* cov3D_ptr = (cov3D_precomp != nullptr) ? cov3D_precomp : geom.cov3D;  // rasterizer_impl.cu:411
@@ -767,8 +806,8 @@ int mi_rast_mask_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                          int height, const float* means3D, const float* opacities, const float* mask,
                          const float* scales, float scale_modifier, const float* rotations,
                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, float tan_fovx,
-                         float tan_fovy, int prefiltered, float* out_mask, int* radii, int debug, void* stream_,
-                         int* num_rendered)
+                         float tan_fovy, int prefiltered, float* out_mask, int* radii, int debug, int flags,
+                         void* stream_, int* num_rendered)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (num_rendered) *num_rendered = 0;
@@ -782,7 +821,7 @@ int mi_rast_mask_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     // DEPTH/cuda_rasterizer/rasterizer_impl.cu:495-521: shs = nullptr, colours "given" (dummy pointer)
     rc = geometry_and_binning(geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P,
                               0, 0, width, height, means3D, nullptr, 1, opacities, scales, rotations, cov3D_precomp, vp,
-                              prefiltered, radii, debug, stream, geom, img, bin, num_rendered);
+                              prefiltered, radii, debug, flags, stream, geom, img, bin, num_rendered);
     if (rc) return rc;
     {
         StageTimer t(stream, MI_STAGE_BLEND_FWD);

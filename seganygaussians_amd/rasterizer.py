@@ -16,7 +16,9 @@ CPU fallback: missing library or non-GPU tensors raise.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import NamedTuple
 
 import torch
@@ -93,6 +95,32 @@ def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# Per-call options of the native forward (include/mi_rast.h: `flags`, `features_ready_event`).  The C library keeps no
+# state between calls; what the reference API has no argument for is held HERE, per host thread, and handed over with
+# each call.
+class _CallOptions(threading.local):
+    def __init__(self):
+        self.flags = 0
+        self.features_ready = None   # torch.cuda.Event, kept alive until the forward that consumes it has returned
+
+
+_opts = _CallOptions()
+
+
+@contextlib.contextmanager
+def forward_flags(full_lists=None, f32_blend=None):
+    """Within the block, forwards of this thread run with the given modes: `full_lists` materialises the reference's
+    point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels."""
+    prev = _opts.flags
+    for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend)):
+        if v is not None:
+            _opts.flags = (_opts.flags | bit) if v else (_opts.flags & ~bit)
+    try:
+        yield
+    finally:
+        _opts.flags = prev
+
+
 def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, colors, opacity, mask, scales,
                                rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                image_height, image_width, sh, degree, campos, prefiltered, debug):
@@ -117,6 +145,12 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
                                    viewmatrix, projmatrix, campos, mask)]
         bg_c, m3_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, vm_c, pm_c, cp_c, mk_c = t
         n = C.c_int(0)
+        ready = _opts.features_ready          # one-shot; cleared whatever happens below
+        _opts.features_ready = None
+        if with_mask_depth and (mk_c is None or mk_c.numel() != P or not mk_c.is_cuda or mk_c.dtype != torch.float32):
+            # the DEPTH package always passes a mask (DEPTH/.../__init__.py:323); without one out_mask / out_depth
+            # would be left unwritten
+            raise RuntimeError("mask must hold one float32 per Gaussian on the GPU (diff_gaussian_rasterization_depth)")
         with torch.cuda.device(dev):
             rc = L.mi_rast_forward(
                 geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), int(channels),
@@ -128,7 +162,9 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
                 int(bool(prefiltered)), _dev_ptr(mk_c, "mask", dev) if with_mask_depth else None,
                 out_color.data_ptr(), out_mask.data_ptr() if with_mask_depth else None,
                 out_depth.data_ptr() if with_mask_depth else None, radii.data_ptr(), int(bool(debug)),
-                _stream_ptr(dev), C.byref(n))
+                int(_opts.flags), None if ready is None else C.c_void_p(ready.cuda_event), _stream_ptr(dev),
+                C.byref(n))
+        del ready
         _check(rc)
         rendered = n.value
     else:
@@ -141,11 +177,12 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
 
 
 def set_features_ready_event(event) -> None:
-    """The next forward's blend stage waits for `event` (a recorded torch.cuda.Event, or None to cancel); everything
-    before it -- preprocess, depth order, binning, per-tile sort -- only reads the geometry and runs ahead.  For training
-    loops that optimise colors_precomp alone (include/mi_rast.h: mi_rast_set_features_ready_event)."""
-    L = _lib.load()
-    L.mi_rast_set_features_ready_event(None if event is None else C.c_void_p(event.cuda_event))
+    """The next forward of this host thread makes its stream wait for `event` (a recorded torch.cuda.Event, or None to
+    cancel) right before its blend stage; everything before it -- preprocess, depth order, binning, per-tile sort -- only
+    reads the geometry and runs ahead.  For training loops that optimise colors_precomp alone.  The event is passed to that
+    one mi_rast_forward call as an argument (include/mi_rast.h: features_ready_event) and a reference is held until it
+    returns; an error in that forward drops it as well."""
+    _opts.features_ready = event
 
 
 def rasterize_gaussians_backward_native(channels, with_mask_depth, background, means3D, radii, colors, scales,
@@ -159,13 +196,17 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
     M = sh.size(1) if sh.numel() != 0 else 0
     dev = means3D.device
     o = dict(device=dev, dtype=torch.float32)
-    # The reference allocates ten zero tensors (rasterize_points.cu:151-159).  Same tensors here, carved from ONE
-    # zero-filled block: one fill launch instead of ten (each small fill costs a launch, ~5 us, on this part).
+    # The reference allocates ten zero tensors (rasterize_points.cu:151-159).  Same tensors here, carved from TWO
+    # zero-filled blocks: two fill launches instead of ten (each small fill costs a launch, ~5 us, on this part).
+    # dL_dcolors -- the one gradient SAGA's feature training keeps (`_point_features.grad`) -- has its own storage, so
+    # holding it does not pin the geometry gradients and the internal scratch (dL_dconic, unused dL_dcov3D / dL_dsh),
+    # which share the second block.
     shapes = [("dL_dmeans3D", (P, 3)), ("dL_dmeans2D", (P, 3)), ("dL_dcolors", (P, channels)), ("dL_dconic", (P, 2, 2)),
               ("dL_dopacity", (P, 1)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)),
               ("dL_drotations", (P, 4))]
     if with_mask_depth:
-        shapes.append(("dL_dmask", (P,)))
+        shapes.append(("dL_dmask", (P, 1)))   # DEPTH/rasterize_points.cu:167: torch::zeros({P, 1})
+    shapes = [x for x in shapes if x[0] != "dL_dcolors"]
     sizes = []
     for _n, shp in shapes:
         n = 1
@@ -173,7 +214,7 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
             n *= d
         sizes.append((n + 3) // 4 * 4)  # keep every tensor 16-byte aligned
     flat = torch.zeros(sum(sizes), **o)
-    g = {}
+    g = {"dL_dcolors": torch.zeros((P, channels), **o)}
     off = 0
     for (name, shp), n in zip(shapes, sizes):
         cnt = 1
@@ -249,7 +290,7 @@ def rasterize_mask_gaussians_native(means3D, opacity, mask, scales, rotations, s
                 float(scale_modifier), _dev_ptr(rot_c, "rotations", dev), _dev_ptr(cov_c, "cov3D_precomp", dev),
                 _dev_ptr(vm_c, "viewmatrix", dev), _dev_ptr(pm_c, "projmatrix", dev), float(tan_fovx),
                 float(tan_fovy), int(bool(prefiltered)), out_mask.data_ptr(), radii.data_ptr(), int(bool(debug)),
-                _stream_ptr(dev), C.byref(n))
+                int(_opts.flags), _stream_ptr(dev), C.byref(n))
         _check(rc)
         rendered = n.value
     else:
@@ -262,7 +303,7 @@ def rasterize_mask_gaussians_backward_native(means3D, dL_dout_mask, geomBuffer, 
     P = means3D.size(0)
     H, W = dL_dout_mask.size(-2), dL_dout_mask.size(-1)
     dev = means3D.device
-    dL_dmask = torch.zeros((P,), dtype=torch.float32, device=dev)
+    dL_dmask = torch.zeros((P, 1), dtype=torch.float32, device=dev)   # DEPTH/rasterize_points.cu:349
     if P != 0:
         d_c = _contig(dL_dout_mask)
         with torch.cuda.device(dev):
@@ -414,6 +455,7 @@ def _make_depth():
             else:
                 res = call()
             num_rendered, color, out_mask, depth, radii, geomBuffer, binningBuffer, imgBuffer = res
+            ctx.mask_shape = mask.shape
             ctx.raster_settings = rs
             ctx.num_rendered = num_rendered
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
@@ -449,6 +491,9 @@ def _make_depth():
                 res = call()
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_mask, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations) = res
+            # the reference hands back (P,1) (DEPTH/rasterize_points.cu:167), which autograd accepts only for a (P,1)
+            # mask; same P values here, shaped like the mask that came in, so that (P,) works as well
+            grad_mask = grad_mask.view(ctx.mask_shape)
             return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_mask, grad_scales,
                     grad_rotations, grad_cov3Ds_precomp, None)
 
@@ -462,6 +507,7 @@ def _make_depth():
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.prefiltered, rs.debug)
             ctx.raster_settings = rs
             ctx.num_rendered = num_rendered
+            ctx.mask_shape = mask.shape
             ctx.save_for_backward(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, radii, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
@@ -473,7 +519,7 @@ def _make_depth():
             (means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, radii, geomBuffer, binningBuffer,
              imgBuffer) = ctx.saved_tensors
             grad_mask = rasterize_mask_gaussians_backward_native(means3D, grad_out_mask, geomBuffer, ctx.num_rendered,
-                                                                 binningBuffer, imgBuffer, rs.debug)
+                                                                 binningBuffer, imgBuffer, rs.debug).view(ctx.mask_shape)
             # only the mask receives a real gradient; the reference hands ZEROS (not None) to every other input
             # (DEPTH/.../__init__.py:278-290) -- kept, but shaped like the inputs so autograd accepts them.
             z = [torch.zeros_like(t) if need else None for t, need in

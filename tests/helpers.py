@@ -86,19 +86,15 @@ class GpuRun:
         self.mask = t(inp.mask)
         self.with_mask = inp.mask is not None
 
-    def forward(self, debug=False, full_lists=True):
+    def forward(self, debug=False, full_lists=True, f32_blend=None):
         """full_lists=True materialises the reference's point_list / full-list positions (what the bit-exact
         comparisons with the oracle read); False is the product default ("lean" lists, include/mi_rast.h)."""
-        from seganygaussians_amd import _lib
         i = self.inp
-        prev = _lib.load().mi_rast_set_full_lists(1 if full_lists else 0)
-        try:
+        with self.R.forward_flags(full_lists=bool(full_lists), f32_blend=f32_blend):
             res = self.R.rasterize_gaussians_native(
                 i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
                 self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,
                 i.image_width, self.shs, i.sh_degree, self.campos, i.prefiltered, debug)
-        finally:
-            _lib.load().mi_rast_set_full_lists(prev)
         self.full_lists = bool(full_lists or debug)
         if self.with_mask:
             (self.num_rendered, self.color, self.out_mask, self.out_depth, self.radii, self.geom, self.binning,

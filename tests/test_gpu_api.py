@@ -141,3 +141,78 @@ def test_features_ready_event_orders_the_blend_stage():
         again, _ = rast(colors_precomp=feats, **kw)   # the event was consumed: plain call
     torch.cuda.synchronize(dev)
     assert torch.equal(got, want) and torch.equal(again, want)
+
+
+def test_reentrant_two_threads_two_streams():
+    """The C-ABI keeps no state between calls: two host threads, each with its own stream, its own scene, its own list mode
+    (one full, one lean with the f32 blend) and its own features-ready event, run forwards + backwards concurrently and get
+    exactly what they get alone."""
+    import threading
+    from seganygaussians_amd import rasterizer as R
+    mod = __import__("diff_gaussian_rasterization_contrastive_f")
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    jobs = []
+    for seed, (W, H), flags in ((41, (304, 208), dict(full_lists=True)), (42, (208, 160), dict(full_lists=False, f32_blend=True))):
+        inp = hp.make_inputs(30_000, W, H, 32, seed=seed, camera="orbit")
+        jobs.append(dict(inp=inp, flags=flags, dL=t(scenes.make_grad_image(32, H, W, seed=seed))))
+
+    def run(job, stream, use_event, rounds, out):
+        inp = job["inp"]
+        rast = mod.GaussianRasterizer(raster_settings=_settings(mod, inp, dev))
+        res = []
+        with torch.cuda.stream(stream), R.forward_flags(**job["flags"]):
+            for _ in range(rounds):
+                feats = t(inp.colors_precomp).requires_grad_(True)
+                m3 = t(inp.means3D).requires_grad_(True)
+                if use_event:
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    R.set_features_ready_event(ev)
+                color, radii = rast(means3D=m3, means2D=torch.zeros_like(m3), shs=None, colors_precomp=feats,
+                                    opacities=t(inp.opacities), scales=t(inp.scales), rotations=t(inp.rotations),
+                                    cov3D_precomp=None)
+                (color * job["dL"]).sum().backward()
+                res.append((color.detach().clone(), radii.clone(), feats.grad.clone(), m3.grad.clone()))
+            stream.synchronize()
+        out.append(res)
+
+    alone = []
+    for job in jobs:
+        run(job, torch.cuda.Stream(device=dev), False, 1, alone)
+    outs = [[], []]
+    threads = [threading.Thread(target=run, args=(job, torch.cuda.Stream(device=dev), True, 6, o)) for job, o in zip(jobs, outs)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for base, o in zip(alone, outs):
+        assert len(o) == 1 and len(o[0]) == 6
+        c0, r0, g0, m0 = base[0]
+        for c, r, g, m in o[0]:
+            assert torch.equal(c, c0) and torch.equal(r, r0)            # forward: bit-identical
+            hp.assert_close("dL_dfeatures (concurrent)", g.cpu().numpy(), g0.cpu().numpy(), rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
+            hp.assert_close("dL_dmeans3D (concurrent)", m.cpu().numpy(), m0.cpu().numpy(), rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
+
+
+def test_depth_package_mask_contract():
+    """DEPTH package: a missing mask raises instead of leaving out_mask / out_depth unwritten; the mask gradient comes back
+    in the shape of the mask that went in -- (P,1) as the reference allocates it (DEPTH/rasterize_points.cu:167), and (P,)."""
+    mod = __import__("diff_gaussian_rasterization_depth")
+    dev = torch.device("cuda:0")
+    inp = hp.make_inputs(3000, 96, 64, 3, seed=51, use_mask=True)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    rast = mod.GaussianRasterizer(raster_settings=_settings(mod, inp, dev))
+    kw = dict(means3D=t(inp.means3D), means2D=t(inp.means3D) * 0, shs=None, colors_precomp=t(inp.colors_precomp),
+              opacities=t(inp.opacities), scales=t(inp.scales), rotations=t(inp.rotations), cov3D_precomp=None)
+    with pytest.raises(RuntimeError, match="mask must hold one float32 per Gaussian"):
+        rast(mask=torch.empty(0, device=dev), **kw)
+    grads = []
+    for shape in ((3000, 1), (3000,)):
+        mask = t(inp.mask).reshape(shape).requires_grad_(True)
+        color, omask, depth, radii = rast(mask=mask, **kw)
+        (omask.sum() * 0.5 + color.sum() * 0.0).backward()
+        assert mask.grad.shape == mask.shape
+        grads.append(mask.grad.reshape(-1).clone())
+    hp.assert_close("dL_dmask (P,1) vs (P,)", grads[1].cpu().numpy(), grads[0].cpu().numpy(), rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
+    assert float(grads[0].abs().max()) > 0

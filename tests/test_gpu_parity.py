@@ -62,16 +62,14 @@ def test_features32_dense():
 
 
 @pytest.mark.parametrize("C", [32, 64])
-def test_features_forward_x3_matches_f32_mfma(monkeypatch, C):
+def test_features_forward_x3_matches_f32_mfma(C):
     """The default 32 / 64-channel forward accumulates on the bf16 matrix pipe with exactly split operands (blend_fwd_x3.h);
-    MI_RAST_ABLATE_FWD=2048 selects the f32-MFMA kernel (a bit-exact fmaf chain).  Same lists, same alpha / T / n_contrib
+    the MI_RAST_F32_BLEND flag selects the f32-MFMA kernel (a bit-exact fmaf chain).  Same lists, same alpha / T / n_contrib
     (bit-identical), and images that differ by rounding of the f32 accumulation only (a few ulp; same distance from the
     fp64-accumulating oracle)."""
     inp = hp.make_inputs(60_000, 640, 360, C, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
     x3 = hp.GpuRun(inp).forward()
-    monkeypatch.setenv("MI_RAST_ABLATE_FWD", "2048")
-    f32 = hp.GpuRun(inp).forward()
-    monkeypatch.delenv("MI_RAST_ABLATE_FWD")
+    f32 = hp.GpuRun(inp).forward(f32_blend=True)
     a, b = x3.color.cpu().numpy().astype(np.float64), f32.color.cpu().numpy().astype(np.float64)
     assert not np.array_equal(a, b), "expected two different kernels (is the switch still wired?)"
     scale = np.abs(b).max()
@@ -130,7 +128,7 @@ def test_mask_only_pair():
     dLm = np.random.default_rng(3).normal(0, 1, (1, inp.image_height, inp.image_width)).astype(np.float32)
     gm = R.rasterize_mask_gaussians_backward_native(g.means3D, torch.as_tensor(dLm).cuda(), geom, nr, binning, img, False)
     want = so.mask_backward(inp, fwd, dLm[0])
-    hp.assert_close("dL_dmask", gm.cpu().numpy(), want, flip_frac=hp.GRAD_FLIP_FRAC)
+    hp.assert_close("dL_dmask", gm.cpu().numpy().reshape(-1), want, flip_frac=hp.GRAD_FLIP_FRAC)
 
 
 def test_mark_visible():
@@ -205,7 +203,9 @@ def test_full_size_cfg3_properties():
     ranges = im["ranges"].reshape(-1, 2).astype(np.int64)
     counts = np.bincount(tiles, minlength=len(ranges))
     np.testing.assert_array_equal(ranges[:, 1] - ranges[:, 0], counts)
-    assert np.all(im["n_contrib"].reshape(-1) <= 200000)
+    # n_contrib is a 1-based position inside the pixel's own tile list
+    tile_of_pix = (np.arange(inp.image_height)[:, None] // 16) * ((inp.image_width + 15) // 16) + np.arange(inp.image_width)[None, :] // 16
+    assert np.all(im["n_contrib"].reshape(inp.image_height, inp.image_width) <= counts[tile_of_pix])
     # linearity in the features (bg = 0): render(2*f1 - 0.5*f2) == 2*render(f1) - 0.5*render(f2)
     c1 = gpu.color.clone()
     f1 = gpu.colors
