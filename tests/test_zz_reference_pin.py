@@ -184,7 +184,7 @@ def test_product_vs_ref_reduced_cfg3_cfg2_cfg5():
     _product_vs_ref(hp.make_inputs(20_000, 320, 208, 64, seed=5, log_scale=math.log(0.04)))
 
 
-def _check_stats(stats, ref_stats, what, row_floor=1e-3):
+def _check_stats(stats, ref_stats, what, row_floor=1e-3, norm_floor=1e-4):
     """Norm-wise and per-row errors of the product (vs the fp64-accumulating oracle or vs the reference) next to the
     reference's own f32-atomic noise against the same yardstick."""
     for k, s in stats.items():
@@ -192,7 +192,7 @@ def _check_stats(stats, ref_stats, what, row_floor=1e-3):
         print(f"{what} {k}: norm {s['norm']:.2e} rows outside {s['row_frac']:.2e} worst {s['row_worst']:.1f}"
               + (f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}" if r else ""))
         assert not s["zero_rows_touched"], f"{what} {k}: a Gaussian the reference leaves at exactly 0 got a gradient"
-        assert s["norm"] <= max(1e-4, 3 * (r["norm"] if r else 0)), (what, k, s, r)
+        assert s["norm"] <= max(norm_floor, 3 * (r["norm"] if r else 0)), (what, k, s, r)
         assert s["row_frac"] <= max(row_floor, 3 * (r["row_frac"] if r else 0)), (what, k, s, r)
 
 
@@ -237,4 +237,5 @@ def test_full_size_cfg5_product_vs_ref():
     assert rf.num_rendered > 25_000_000
     # two f32-atomic runs against each other (no fp64 yardstick at this size): the reference's own rows-outside fraction
     # against the fp64 oracle is 1.2e-3 .. 1.8e-3 for cov3D / scales / rotations on cfg3, so twice that is the floor here
-    _check_stats(rep["stats"], None, "cfg5 product-vs-ref", row_floor=4e-3)
+    # (norm-wise: the rotation gradient of the reference itself sits at 3.7e-5 of the fp64 oracle on cfg3, 1.3e-4 on cfg5)
+    _check_stats(rep["stats"], None, "cfg5 product-vs-ref", row_floor=4e-3, norm_floor=5e-4)
