@@ -18,6 +18,7 @@
 #include "knn_smooth.h"
 #include "blend_bwd.h"
 #include "blend_bwd_mfma.h"
+#include "blend_bwd_wave.h"
 #include "blend_fwd.h"
 #include "blend_fwd_x3.h"
 #include "common.h"
@@ -752,22 +753,51 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     hipLaunchKernelGGL((blend_bwd_mfma_kernel<__VA_ARGS__>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,    \
                        bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib, dL_dpix, \
                        dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
+        const uint32_t nt_ = vp.grid_x * vp.grid_y;
+#define LAUNCH_BWD_WAVE_(WPB, ...)                                                                                        \
+    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB>), dim3(WPB == 1 ? ((nt_ + 7u) / 8u) * 32u : nt_), dim3(64 * WPB), 0, \
+                       stream, img.ranges, bin.blend_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, background, color_ptr, \
+                       img.final_T, img.n_contrib, dL_dpix, dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
+#define LAUNCH_BWD_WAVE(...)                                                    \
+    do {                                                                        \
+        if (g_ablate & 4096) LAUNCH_BWD_WAVE_(4, __VA_ARGS__);                  \
+        else LAUNCH_BWD_WAVE_(1, __VA_ARGS__);                                  \
+    } while (0)
 #ifdef MI_RAST_PROFILING
-        if (g_ablate & 1024) {  // the VALU kernels (timing comparisons)
+        if (g_ablate & 2048) {  // the tile-batched MFMA kernel (blend_bwd_mfma.h), for comparisons
+            if (maskgrad) LAUNCH_BWD_MFMA(16, 3, true);
+            else if (channels == 3) LAUNCH_BWD_MFMA(16, 3, false);
+            else if (channels == 32) LAUNCH_BWD_MFMA(32);
+            else LAUNCH_BWD_MFMA(64);
+        } else if (g_ablate & 1024) {  // the VALU kernels (timing comparisons)
             if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor);
             else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
             else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
             else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
         } else
 #endif
-        if (maskgrad) LAUNCH_BWD_MFMA(16, 3, true);
-        else if (channels == 3) LAUNCH_BWD_MFMA(16, 3, false);
-        else if (channels == 32) LAUNCH_BWD_MFMA(32);
-        else LAUNCH_BWD_MFMA(64);
+        if (maskgrad) LAUNCH_BWD_WAVE(16, 3, true);
+        else if (channels == 3) LAUNCH_BWD_WAVE(16, 3, false);
+        else if (channels == 32) LAUNCH_BWD_WAVE(32, 32, false);
+        else LAUNCH_BWD_WAVE(64, 64, false);
+#undef LAUNCH_BWD_WAVE
+#undef LAUNCH_BWD_WAVE_
 #undef LAUNCH_BWD_MFMA
     }
 #ifdef MI_RAST_PROFILING
-    if (g_ablate & 32) {
+    if ((g_ablate & 32) && !(g_ablate & 2048)) {
+        float dbg[8 * 13];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);
+        const char* nm[9] = {"header", "dL staging", "first fill+request", "stage(wait+write)", "scan+request", "S mfma+transpose",
+                             "recurrences", "dF/M mfma", "outputs"};
+        double tot = 0;
+        for (int i = 0; i < 9; i++) tot += dbg[8 * (i + 1) + 7];
+        fprintf(stderr, "[mi_rast debug] bwd wave kernel: %.0f waves, %.0f chunks, %.0f scan blocks; wave-cycles %.4g:", dbg[8 * 12 + 7], dbg[8 * 10 + 7],
+                dbg[8 * 11 + 7], tot);
+        for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * dbg[8 * (i + 1) + 7] / tot);
+        fprintf(stderr, "\n");
+    } else if (g_ablate & 32) {
         float dbg[88];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);

@@ -23,6 +23,11 @@ __global__ void k(float* buf, uint32_t rows, int iters, int stride_rows)
         if (MODE == 4) { if (lane < 32) atomicAdd(p + lane, 1.0f); }
         if (MODE == 5) { if (lane < 32) p[lane] += 1.0f; }                          // plain RMW (no atomic) for reference
         if (MODE == 6) { if (lane < 8) atomicAdd(p + lane, 1.0f); }                 // 8 lanes, one 32-B sector
+        // the blend backward's real instruction shapes: every lane group of one instruction goes to a different random row
+        if (MODE == 7) { const uint32_t r4 = hash32(row * 4 + (lane >> 4)) % rows; atomicAdd(buf + (size_t)r4 * 32 + (lane & 15) + 16 * (it & 1), 1.0f); }  // 4 rows x 64 B
+        if (MODE == 8) { const uint32_t r2 = hash32(row * 2 + (lane >> 5)) % rows; atomicAdd(buf + (size_t)r2 * 32 + (lane & 31), 1.0f); }                  // 2 rows x 128 B
+        if (MODE == 9) { const uint32_t r8 = hash32(row * 8 + (lane >> 3)) % rows; atomicAdd(buf + (size_t)r8 * 8 + (lane & 7), 1.0f); }                    // 8 rows x 32 B
+        if (MODE == 10) { const uint32_t r8 = hash32(row * 8 + (lane >> 3)) % rows; if ((lane & 7) < 6) atomicAdd(buf + (size_t)r8 * 8 + (lane & 7), 1.0f); }  // 8 rows x 24 B
     }
 }
 
@@ -52,5 +57,9 @@ int main()
     run<4>("32 lanes -> one line, sequential rows", buf, rows, 32);
     run<5>("32 lanes plain RMW (no atomic)", buf, rows, 32);
     run<6>("8 lanes -> 32B", buf, rows, 8);
+    run<7>("64 lanes -> 4 random rows x 64B", buf, rows, 64);
+    run<8>("64 lanes -> 2 random rows x 128B", buf, rows, 64);
+    run<9>("64 lanes -> 8 random rows x 32B", buf, rows, 64);
+    run<10>("48 lanes -> 8 random rows x 24B", buf, rows, 48);
     return 0;
 }
