@@ -26,7 +26,7 @@ def short(n):
     return n[:90]
 
 
-STAGE_OF = {"blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_mfma_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "blend_fwd_x3_kernel": "blend_fwd",
+STAGE_OF = {"blend_bwd_wave_kernel": "blend_bwd", "blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_mfma_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "blend_fwd_x3_kernel": "blend_fwd",
             "preprocess_fwd_kernel": "preprocess", "bin_ranks_kernel<true, false>": "emit", "tile_sort_kernel": "tile_sort",
             "bin_ranks_kernel<false, false>": "tile_scan", "bin_count_kernel<false>": "tile_scan", "bin_count_kernel": "tile_scan", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
             "depth_bucket_kernel<false>": "depth_sort", "depth_bucket_kernel<true>": "depth_sort",
@@ -90,6 +90,22 @@ with open(os.path.join(dst, f"{tag}_pmc.md"), "w") as f:
             for c, v in sorted(cs.items()):
                 f.write(f"| {c} | {sum(v)/len(v):.0f} |\n")
             f.write("\n")
+# matrix / vector pipe busy fractions of the blend kernels (bench.py: roofline.alu).  SIMD-cycles of a dispatch =
+# GRBM_GUI_ACTIVE (summed over the 8 XCDs by rocprofv3) / 8 x 1024 SIMDs; SQ_VALU_MFMA_BUSY_CYCLES is in cycles,
+# SQ_ACTIVE_INST_VALU in quad-cycles.
+alu = {}
+sq1, sq2 = pmc("sq1"), pmc("sq2")
+avg = lambda d, k: (sum(d[k]) / len(d[k])) if k in d and d[k] else None
+for k in set(sq1) & set(sq2):
+    st = STAGE_OF.get(k)
+    gui, mf, va = avg(sq2[k], "GRBM_GUI_ACTIVE"), avg(sq2[k], "SQ_VALU_MFMA_BUSY_CYCLES"), avg(sq1[k], "SQ_ACTIVE_INST_VALU")
+    if not st or not gui:
+        continue
+    simd_cycles = gui / 8.0 * 1024.0
+    alu[st] = {"kernel": k, "mfma_busy_frac": round((mf or 0) / simd_cycles, 4), "valu_busy_frac": round(4.0 * (va or 0) / simd_cycles, 4),
+               "lds_bank_conflict_frac": round((avg(sq2[k], "SQ_LDS_BANK_CONFLICT") or 0) / max(1.0, avg(sq2[k], "SQ_LDS_IDX_ACTIVE") or 1.0), 4),
+               "source": f"profiles/{tag}_pmc.md"}
+json.dump(alu, open(os.path.join(dst, "alu.json"), "w"), indent=1)
 for st in traffic.values():
     st["bytes_per_launch"] = round(st["bytes_per_launch"])
 traffic["_source"] = f"profiles/{tag}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note)"
