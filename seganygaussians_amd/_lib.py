@@ -22,6 +22,7 @@ EXPORTS = [
     "mi_rast_get_higher_msb", "mi_rast_geometry_layout", "mi_rast_image_layout", "mi_rast_binning_layout",
     "mi_rast_profile_enable", "mi_rast_profile_read",
     "mi_knn_smooth_forward", "mi_knn_smooth_backward",  # include/mi_knn_smooth.h
+    "mi_knn_workspace_bytes", "mi_knn_build", "mi_knn_query", "mi_knn_mean_dist2",  # include/mi_knn.h
 ]
 
 _lib = None
@@ -84,6 +85,14 @@ def load():
     L.mi_knn_smooth_forward.argtypes = [i, i, i, vp, u32, vp, vp, i, vp]
     L.mi_knn_smooth_backward.restype = i
     L.mi_knn_smooth_backward.argtypes = [i, i, i, vp, vp, vp, u32, vp, vp, vp, vp, i, vp]
+    L.mi_knn_workspace_bytes.restype = C.c_size_t
+    L.mi_knn_workspace_bytes.argtypes = [i]
+    L.mi_knn_build.restype = i
+    L.mi_knn_build.argtypes = [i, vp, vp, C.c_size_t, vp]
+    L.mi_knn_query.restype = i
+    L.mi_knn_query.argtypes = [i, vp, i, vp, i, i, vp, vp, vp]
+    L.mi_knn_mean_dist2.restype = i
+    L.mi_knn_mean_dist2.argtypes = [i, vp, vp, C.c_size_t, vp, vp]
     _lib = L
     return L
 

@@ -3,9 +3,11 @@
 // -munsafe-fp-atomics -fPIC -shared (see seganygaussians_amd/build.py).  No torch, no pybind.
 #include "../../include/mi_rast.h"
 #include "../../include/mi_knn_smooth.h"
+#include "../../include/mi_knn.h"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +18,7 @@
 #include "binning.h"
 #include "depth_sort.h"
 #include "knn_smooth.h"
+#include "knn.h"
 #include "blend_bwd.h"
 #include "blend_bwd_mfma.h"
 #include "blend_bwd_wave.h"
@@ -526,6 +529,45 @@ void launch_blend_bwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& i
 
 }  // namespace
 
+namespace {
+struct KnnWs {
+    uint32_t* bbox;        // [8]
+    uint32_t* codes[2];    // [M] ping-pong
+    uint32_t* index[2];    // [M]
+    uint32_t* hist;        // [256 * nblocks]
+    float4* sorted_pts;    // [M]
+    KnnBox* leaves;        // [nleaf]
+    KnnBox* supers;        // [nsuper]
+    size_t bytes;
+};
+KnnWs knn_carve(char* base, int M)
+{
+    const size_t m = M > 0 ? (size_t)M : 1;
+    const size_t nblocks = (m + KNN_TILE - 1) / KNN_TILE;
+    const size_t nleaf = (m + KNN_LEAF - 1) / KNN_LEAF, nsuper = (nleaf + KNN_FAN - 1) / KNN_FAN;
+    Carver c;
+    KnnWs w;
+    w.bbox = (uint32_t*)(base + c.take(8 * sizeof(uint32_t)));
+    for (int k = 0; k < 2; k++) w.codes[k] = (uint32_t*)(base + c.take(m * sizeof(uint32_t)));
+    for (int k = 0; k < 2; k++) w.index[k] = (uint32_t*)(base + c.take(m * sizeof(uint32_t)));
+    w.hist = (uint32_t*)(base + c.take(256 * nblocks * sizeof(uint32_t)));
+    w.sorted_pts = (float4*)(base + c.take(m * sizeof(float4)));
+    w.leaves = (KnnBox*)(base + c.take(nleaf * sizeof(KnnBox)));
+    w.supers = (KnnBox*)(base + c.take(nsuper * sizeof(KnnBox)));
+    w.bytes = c.off;
+    return w;
+}
+}  // namespace
+
+namespace {
+template <int K, bool SELF, bool MEAN3>
+void knn_launch(int rows, const float* query, int M, const KnnWs& w, int exclude_self, int64_t* idx, float* d2, hipStream_t stream)
+{
+    hipLaunchKernelGGL((knn_query_kernel<K, SELF, MEAN3>), dim3((rows + 63) / 64), dim3(64), 0, stream, rows, query, M, w.sorted_pts,
+                       w.codes[0], w.bbox, w.leaves, w.supers, exclude_self, idx, d2);
+}
+}  // namespace
+
 extern "C" {
 
 const char* mi_rast_last_error(void) { return g_last_error.c_str(); }
@@ -578,6 +620,74 @@ int mi_knn_smooth_backward(int P, int C, int K, const int* knn_idx, const int* i
         hipLaunchKernelGGL(knn_smooth_bwd_mean_kernel<64>, grid, dim3(256), 0, stream, P, K, knn_idx, mask, 1.0f / (float)k, features, dL_dout, dmean, normalize_out);
         hipLaunchKernelGGL(knn_smooth_bwd_feat_kernel<64>, grid, dim3(256), 0, stream, P, inv_offsets, inv_entries, mask, features, dmean, dL_dfeatures);
     }
+    HIP_TRY(hipGetLastError());
+    return MI_RAST_OK;
+}
+
+
+// ---- exact KNN (mi_knn.h, knn.h) ---------------------------------------------------------------------------------------
+
+size_t mi_knn_workspace_bytes(int M) { return knn_carve(nullptr, M).bytes; }
+
+int mi_knn_build(int M, const float* ref, void* workspace, size_t workspace_bytes, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M <= 0 || !ref || !workspace) return fail(MI_RAST_ERR_INVALID, "knn: need M > 0, reference points and a workspace");
+    const KnnWs w = knn_carve((char*)workspace, M);
+    if (workspace_bytes < w.bytes) return fail(MI_RAST_ERR_INVALID, "knn: workspace smaller than mi_knn_workspace_bytes(M)");
+    const int nblocks = (M + KNN_TILE - 1) / KNN_TILE;
+    const int nleaf = (M + KNN_LEAF - 1) / KNN_LEAF, nsuper = (nleaf + KNN_FAN - 1) / KNN_FAN;
+    hipLaunchKernelGGL(knn_init_kernel, dim3(1), dim3(64), 0, stream, w.bbox);
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(std::min(1024, (M + 255) / 256)), dim3(256), 0, stream, M, ref, w.bbox);
+    hipLaunchKernelGGL(knn_morton_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, M, ref, w.bbox, w.codes[0], w.index[0]);
+    for (int pass = 0; pass < 4; pass++) {  // 30-bit codes: four 8-bit digits
+        const int a = pass & 1, b = a ^ 1;
+        hipLaunchKernelGGL(knn_radix_hist_kernel, dim3(nblocks), dim3(256), 0, stream, M, w.codes[a], 8 * pass, nblocks, w.hist);
+        hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, stream, 256 * nblocks, w.hist);
+        hipLaunchKernelGGL(knn_radix_scatter_kernel, dim3(nblocks), dim3(256), 0, stream, M, w.codes[a], w.index[a], 8 * pass, nblocks,
+                           w.hist, w.codes[b], w.index[b]);
+    }
+    // four passes: the sorted pairs are back in buffer 0
+    hipLaunchKernelGGL(knn_leaf_kernel, dim3(nleaf), dim3(KNN_LEAF), 0, stream, M, ref, w.index[0], w.sorted_pts, w.leaves);
+    hipLaunchKernelGGL(knn_super_kernel, dim3(nsuper), dim3(KNN_FAN), 0, stream, nleaf, w.leaves, w.supers);
+    HIP_TRY(hipGetLastError());
+    return MI_RAST_OK;
+}
+
+
+int mi_knn_query(int N, const float* query, int M, const void* workspace, int K, int exclude_self, int64_t* idx,
+                 float* dist2, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M <= 0 || !workspace || !idx || !dist2) return fail(MI_RAST_ERR_INVALID, "knn: need M > 0, an index and output buffers");
+    if (K < 1 || K > MI_KNN_MAX_K) return fail(MI_RAST_ERR_INVALID, "knn: 1 <= K <= 32");
+    const KnnWs w = knn_carve((char*)const_cast<void*>(workspace), M);
+    const bool self = query == nullptr;
+    const int rows = self ? M : N;
+    if (rows <= 0) return MI_RAST_OK;
+    // the kernels keep a list of KT >= K candidates; they write KT columns, so K must be one of the compiled sizes
+    if (K != 1 && K != 3 && K != 4 && K != 8 && K != 16 && K != 32)
+        return fail(MI_RAST_ERR_INVALID, "knn: K must be one of 1, 3, 4, 8, 16, 32");
+#define KNN_DISPATCH(KT)                                                                          \
+    if (K == KT) {                                                                                \
+        if (self) knn_launch<KT, true, false>(rows, nullptr, M, w, exclude_self, idx, dist2, stream); \
+        else knn_launch<KT, false, false>(rows, query, M, w, 0, idx, dist2, stream);              \
+    }
+    KNN_DISPATCH(1) KNN_DISPATCH(3) KNN_DISPATCH(4) KNN_DISPATCH(8) KNN_DISPATCH(16) KNN_DISPATCH(32)
+#undef KNN_DISPATCH
+    HIP_TRY(hipGetLastError());
+    return MI_RAST_OK;
+}
+
+int mi_knn_mean_dist2(int P, const float* points, void* workspace, size_t workspace_bytes, float* out, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0) return MI_RAST_OK;
+    if (!out) return fail(MI_RAST_ERR_INVALID, "knn: null output");
+    const int rc = mi_knn_build(P, points, workspace, workspace_bytes, stream_);
+    if (rc) return rc;
+    const KnnWs w = knn_carve((char*)workspace, P);
+    knn_launch<3, true, true>(P, nullptr, P, w, 1, nullptr, out, stream);
     HIP_TRY(hipGetLastError());
     return MI_RAST_OK;
 }

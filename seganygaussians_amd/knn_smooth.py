@@ -10,7 +10,8 @@ re-normalisation of its result (gaussian_renderer/__init__.py:362-363):
 
 as ONE gather kernel forward and two gather kernels backward (no (P, k, C) tensor, no index_put atomics).
 The neighbour map itself is built once and cached by the reference (pytorch3d.ops.knn_points, absent here);
-`knn_points_bruteforce` is a small-P stand-in for tests, `NeighbourMap` caches the map and its inverse lists.
+`NeighbourMap` caches the map and its inverse lists (`NeighbourMap.from_points` builds it with the exact HIP KNN of
+seganygaussians_amd/knn.py); `knn_points_bruteforce` is the exhaustive checker the tests use.
 There is no CPU path: CPU tensors raise."""
 from __future__ import annotations
 
@@ -43,6 +44,15 @@ class NeighbourMap:
         off[1:] = torch.cumsum(counts, 0)
         self.inv_offsets = off.to(torch.int32).contiguous()
         self.inv_entries = (((order // K) << 5) | (order % K)).to(torch.int32).contiguous()  # uint32 bit pattern
+
+
+    @classmethod
+    def from_points(cls, xyz: torch.Tensor, K: int = 16) -> "NeighbourMap":
+        """The map SAGA builds once per scene: `pytorch3d.ops.knn_points(xyz[None], xyz[None], K=K).idx.squeeze()`
+        (gaussian_model_ff.py:345-352), here by the exact HIP search (seganygaussians_amd/knn.py)."""
+        from .knn import KnnIndex
+        idx, _ = KnnIndex(xyz).query(None, K)
+        return cls(idx)
 
 
 def _mask_of(K: int, cols) -> int:
@@ -116,8 +126,8 @@ def get_smoothed_point_features(features: torch.Tensor, nmap: NeighbourMap, K: i
 
 def knn_points_bruteforce(xyz: torch.Tensor, K: int, chunk: int = 4096) -> torch.Tensor:
     """K nearest neighbours (self included, nearest first) by chunked exhaustive search: what
-    pytorch3d.ops.knn_points(xyz[None], xyz[None], K=K).idx.squeeze() returns.  O(P^2): a stand-in for
-    small P (tests, demos); the one-off map build of a real scene is outside the hot path."""
+    pytorch3d.ops.knn_points(xyz[None], xyz[None], K=K).idx.squeeze() returns.  O(P^2): the CHECKER of the HIP search
+    (seganygaussians_amd/knn.py) in the tests; build_neighbour_map uses the HIP search."""
     P = xyz.size(0)
     out = torch.empty((P, K), dtype=torch.int64, device=xyz.device)
     for s in range(0, P, chunk):

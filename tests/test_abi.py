@@ -19,7 +19,7 @@ def lib():
 
 
 def test_header_symbols_exported(lib):
-    hdr = open(os.path.join(ROOT, "include", "mi_rast.h")).read() + open(os.path.join(ROOT, "include", "mi_knn_smooth.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("mi_rast.h", "mi_knn_smooth.h", "mi_knn.h"))
     declared = set(re.findall(r"\b(mi_(?:rast|knn)_[a-z_0-9]+)\s*\(", hdr)) - {"mi_rast_resize_fn", "mi_rast_last_error"} | {"mi_rast_last_error"}
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:

@@ -56,9 +56,15 @@ def test_channel_counts():
     assert (b.NUM_CHANNELS, cf.NUM_CHANNELS, d.NUM_CHANNELS) == (3, 32, 3)
 
 
-def test_simple_knn_shim():
+def test_knn_dropin_names_and_no_cpu_fallback():
+    """`simple_knn._C.distCUDA2` and `pytorch3d.ops.knn_points` resolve to the HIP search (values: tests/test_knn.py, GPU);
+    like the rasterizer they have no CPU path."""
     from simple_knn._C import distCUDA2
+    import pytorch3d.ops
+    from seganygaussians_amd import knn
+    assert distCUDA2 is knn.distCUDA2 and pytorch3d.ops.knn_points is knn.knn_points
     pts = torch.tensor([[0.0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3], [5, 5, 5]])
-    d = distCUDA2(pts)
-    assert d.shape == (5,)
-    assert abs(float(d[0]) - (1 + 4 + 9) / 3) < 1e-5
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        distCUDA2(pts)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        pytorch3d.ops.knn_points(pts[None], pts[None], K=3)

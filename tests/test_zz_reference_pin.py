@@ -239,3 +239,17 @@ def test_full_size_cfg5_product_vs_ref():
     # against the fp64 oracle is 1.2e-3 .. 1.8e-3 for cov3D / scales / rotations on cfg3, so twice that is the floor here
     # (norm-wise: the rotation gradient of the reference itself sits at 3.7e-5 of the fp64 oracle on cfg3, 1.3e-4 on cfg5)
     _check_stats(rep["stats"], None, "cfg5 product-vs-ref", row_floor=4e-3, norm_floor=5e-4)
+
+
+def test_dist_cuda2_vs_reference_simple_knn():
+    """distCUDA2 of the product (include/mi_knn.h) against the reference's own SimpleKNN::knn (oracle/_ref knn build,
+    submodules/simple-knn/simple_knn.cu:185-218): both are exact searches with the same unfused distance expression."""
+    import torch
+    from seganygaussians_amd import knn
+    rng = np.random.default_rng(0)
+    c = rng.normal(0, 3, (30, 3))
+    pts = (c[rng.integers(0, 30, 200_000)] + rng.normal(0, 0.2, (200_000, 3))).astype(np.float32)
+    want = sr.knn_mean_dist2(pts)
+    got = knn.distCUDA2(torch.as_tensor(pts).cuda()).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-6, atol=0)
+    assert (got != want).mean() < 1e-3, (got != want).mean()   # ties between the 3rd and 4th neighbour only
