@@ -136,15 +136,49 @@ def build_knn(force: bool = False, verbose: bool = False) -> str:
     return out
 
 
+# The reference's Python CALLERS of the rasterizer -- north_star: "render.py / train_contrastive_feature.py call it unchanged" --
+# byte-compiled (py_compile) from where they lie, for tests/test_zz_reference_callers.py: the test box has no /root/reference,
+# and reference sources are never copied into this repository; the .pyc files in oracle/_ref/pyref/ are build outputs like the
+# shared objects above (git-ignored, shipped by gpurun).
+PYREF_MODULES = {
+    "gaussian_renderer": "gaussian_renderer/__init__.py",       # render, render_mask, render_with_depth, render_contrastive_feature
+    "scene.gaussian_model": "scene/gaussian_model.py",          # GaussianModel (activations, get_* properties)
+    "scene.gaussian_model_ff": "scene/gaussian_model_ff.py",    # FeatureGaussianModel (+ KNN feature smoothing)
+    "scene.cameras": "scene/cameras.py",                        # Camera (matrix conventions)
+    "utils.sh_utils": "utils/sh_utils.py",
+    "utils.general_utils": "utils/general_utils.py",
+    "utils.graphics_utils": "utils/graphics_utils.py",
+    "utils.system_utils": "utils/system_utils.py",
+}
+PYREF_DIR = os.path.join(OUT_DIR, "pyref")
+
+
+def pyref_path(module: str) -> str:
+    return os.path.join(PYREF_DIR, module + ".pyc")
+
+
+def build_pyref(force: bool = False):
+    import py_compile
+    os.makedirs(PYREF_DIR, exist_ok=True)
+    out = []
+    for mod, rel in PYREF_MODULES.items():
+        src, dst = os.path.join(REF_ROOT, rel), pyref_path(mod)
+        if force or not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+            py_compile.compile(src, cfile=dst, dfile=f"<reference>/{rel}", doraise=True)
+        out.append(dst)
+    return out
+
+
 def build_all(force: bool = False, verbose: bool = False):
     """Builds every variant when /root/reference is present (the build container); on the GPU box the prebuilt
     files in oracle/_ref/ are used as they are."""
     if not reference_present():
-        return [p for p in (lib_path(v) for v in list(VARIANTS) + ["knn"]) if os.path.exists(p)]
+        return [p for p in [lib_path(v) for v in list(VARIANTS) + ["knn"]] + [pyref_path(m) for m in PYREF_MODULES]
+                if os.path.exists(p)]
     from concurrent.futures import ThreadPoolExecutor          # one hipcc per variant, about a minute each
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         futs = [ex.submit(build_variant, v, force, verbose) for v in VARIANTS] + [ex.submit(build_knn, force, verbose)]
-        return [f.result() for f in futs]
+        return [f.result() for f in futs] + build_pyref(force)
 
 
 if __name__ == "__main__":
