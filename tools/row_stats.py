@@ -1,0 +1,35 @@
+"""How many (quadrant, record) rows the backward walks on cfg3, and how many distinct (tile, record) pairs they are
+(run on the GPU box): decides whether a tile-level reduction in front of the gradient atomics could pay."""
+import numpy as np, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import helpers as hp
+from seganygaussians_amd import _lib
+inp = hp.inputs_from_config("cfg3")
+g = hp.GpuRun(inp).forward(full_lists=False)
+W, H = inp.image_width, inp.image_height
+tx, ty = (W + 15) // 16, (H + 15) // 16
+R = g.num_rendered
+_, off = _lib.binning_layout(R)
+_, ioff = _lib.image_layout(W, H)
+rec = g._view(g.binning, off["blend_rec"], 8 * R, np.uint32).reshape(R, 8)
+im = g.img_fields()
+ranges = im["ranges"].reshape(-1, 2).astype(np.int64)
+nsurv = g._view(g.img, ioff["tile_nsurv"], tx * ty, np.uint32).astype(np.int64)
+nc = im["n_contrib"].reshape(H, W).astype(np.int64)
+pad = np.zeros((ty * 16, tx * 16), np.int64); pad[:H, :W] = nc
+Lq = pad.reshape(ty, 2, 8, tx, 2, 8).max(axis=(2, 5))          # [ty, qy, tx, qx]
+rows = pairs = recs = 0
+multi = np.zeros(5, np.int64)
+for t in range(tx * ty):
+    a, n = ranges[t, 0], nsurv[t]
+    if n == 0: continue
+    pm = rec[a:a + n, 3].astype(np.int64)
+    pos, mask = pm >> 4, pm & 15
+    y, x = divmod(t, tx)
+    hit = np.zeros(n, np.int64)
+    for q in range(4):
+        lt = Lq[y, q >> 1, x, q & 1]
+        hit += (((mask >> q) & 1) == 1) & (pos < lt)
+    rows += hit.sum(); pairs += (hit > 0).sum(); recs += n
+    multi += np.bincount(hit, minlength=5)[:5]
+print(f"records walked {recs}, (quadrant, record) rows {rows}, distinct (tile, record) pairs {pairs}; records by number of quadrants 0..4: {multi.tolist()}")
