@@ -216,3 +216,20 @@ def test_depth_package_mask_contract():
         grads.append(mask.grad.reshape(-1).clone())
     hp.assert_close("dL_dmask (P,1) vs (P,)", grads[1].cpu().numpy(), grads[0].cpu().numpy(), rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
     assert float(grads[0].abs().max()) > 0
+
+
+def test_bench_single_rank_rccl_step():
+    """The N > 1 step of bench.py -- asynchronous RCCL all-reduce of the feature gradients, the next view's geometry stages
+    running ahead of it behind the features-ready event -- on a single-rank process group (the only multi-GPU path a 1-GPU
+    box can execute); reduced Gaussian count, parity of the run checked by the JSON line's own fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dist-single", "--steps", "4", "--warmup", "2",
+                          "--points", "200000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["counters"]["P"] == 200000
+    assert set(line["roofline"]["stages"]) >= {"preprocess", "blend_fwd", "blend_bwd", "geom_bwd"}
