@@ -47,6 +47,9 @@ extern "C" {
 
 /* `flags` of mi_rast_forward / mi_rast_mask_forward (0 = product default). */
 #define MI_RAST_FULL_LISTS 1   /* also materialise the reference's point_list and full-list positions (see below) */
+#define MI_RAST_NO_CULL 4      /* testing aid: the exact-conservative cull is switched off -- every overlap of the reference's
+                                  tile lists reaches the blend kernels with all four quadrant bits (implies full lists).
+                                  Results must not change: images bit for bit, gradients up to the order of the atomic sums */
 #define MI_RAST_F32_BLEND 2    /* 32/64-channel forward on the f32 FMA-chain kernel instead of the exactly split bf16x3
                                   matrix kernel (same alpha/T/n_contrib bit for bit; images agree to a few ulp) */
 

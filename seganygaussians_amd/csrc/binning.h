@@ -254,7 +254,8 @@ inline int bin_workgroups(int P)
 // the tile's segment; the per-tile sort drops the zeros and never materialises point_list.  Both passes then walk
 // only the part of each rect that the cull can keep (shrink_rect): counts, ranges and segments are upper bounds of
 // the lean lists, not the reference's.
-template <bool EMIT, bool FULL = true>
+// NOCULL (testing aid, MI_RAST_NO_CULL): every overlap of the reference's lists is kept with all four quadrant bits.
+template <bool EMIT, bool FULL = true, bool NOCULL = false>
 __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
                                                                 uint32_t* __restrict__ partial,
                                                                 const uint2* __restrict__ ranges,
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
             for_each_tile_balanced<true>(
                 rw, tid, rmin, rmax, count, s_queue + wave * 128,
                 [&](uint32_t owner, uint32_t tx, uint32_t ty) {
-                    if (tile_may_blend(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y))) return true;
+                    if (NOCULL || tile_may_blend(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y))) return true;
                     if (FULL) {
                         const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
                         entries[slot] = rank_of(owner);
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
                     return false;
                 },
                 [&](uint32_t owner, uint32_t tx, uint32_t ty) {
-                    const uint32_t qmask = quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
+                    const uint32_t qmask = NOCULL ? 15u : quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
                     if (!FULL && qmask == 0u) return;
                     const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
                     entries[slot] = rank_of(owner) | (qmask << RANK_BITS);

@@ -364,6 +364,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -406,7 +407,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     STAGE_CHECK("depth sort");
     // Full lists (the reference's point_list and full-list positions) are materialised on request -- the reference's
     // `debug` flag or MI_RAST_FULL_LISTS -- ; otherwise only the overlaps that pass the cull are listed.
-    const bool full = debug != 0 || (flags & MI_RAST_FULL_LISTS) != 0;
+    const bool nocull = (flags & MI_RAST_NO_CULL) != 0;
+    const bool full = debug != 0 || nocull || (flags & MI_RAST_FULL_LISTS) != 0;
     const int nwg = bin_workgroups(P);
     const size_t bin_lds = ((size_t)((ntiles + 3) & ~3) + 3 * 1024 + 16) * sizeof(uint32_t);
     {
@@ -455,7 +457,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            if (full) {
+            if (nocull) {
+                hipLaunchKernelGGL((bin_ranks_kernel<true, true, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P,
+                                   geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
+            } else if (full) {
                 hipLaunchKernelGGL((bin_ranks_kernel<true, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P,
                                    geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
             } else {

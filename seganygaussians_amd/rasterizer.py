@@ -108,11 +108,11 @@ _opts = _CallOptions()
 
 
 @contextlib.contextmanager
-def forward_flags(full_lists=None, f32_blend=None):
+def forward_flags(full_lists=None, f32_blend=None, no_cull=None):
     """Within the block, forwards of this thread run with the given modes: `full_lists` materialises the reference's
-    point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels."""
+    point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels, `no_cull` switches the exact-conservative cull off (testing aid)."""
     prev = _opts.flags
-    for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend)):
+    for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend), (_lib.MI_RAST_NO_CULL, no_cull)):
         if v is not None:
             _opts.flags = (_opts.flags | bit) if v else (_opts.flags & ~bit)
     try:

@@ -86,11 +86,11 @@ class GpuRun:
         self.mask = t(inp.mask)
         self.with_mask = inp.mask is not None
 
-    def forward(self, debug=False, full_lists=True, f32_blend=None):
+    def forward(self, debug=False, full_lists=True, f32_blend=None, no_cull=None):
         """full_lists=True materialises the reference's point_list / full-list positions (what the bit-exact
         comparisons with the oracle read); False is the product default ("lean" lists, include/mi_rast.h)."""
         i = self.inp
-        with self.R.forward_flags(full_lists=bool(full_lists), f32_blend=f32_blend):
+        with self.R.forward_flags(full_lists=bool(full_lists), f32_blend=f32_blend, no_cull=no_cull):
             res = self.R.rasterize_gaussians_native(
                 i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
                 self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,

@@ -262,3 +262,44 @@ def test_long_tile_lists_all_sort_classes():
                          z_range=(2.0, 9.0))
     rep, gpu, fwd = _fwd_bwd(inp)
     assert 2048 < _max_tile_list(gpu) <= 12288, _max_tile_list(gpu)
+
+
+@pytest.mark.parametrize("case", ["rgb", "features32", "depth"])
+def test_cull_is_exactly_conservative(case):
+    """MI_RAST_NO_CULL hands EVERY overlap of the reference's tile lists to the blend kernels (all four quadrant bits).  The
+    exact-conservative cull may only ever drop pairs that cannot reach alpha >= 1/255 anywhere in their quadrant, so the
+    image, final_T, n_contrib, mask and depth must be BIT-IDENTICAL with and without it (a wrongly culled pair at
+    alpha ~ 1/255 would move a pixel by ~0.4 %: no tolerance could tell that from a threshold flip), the integer path is
+    untouched, and the gradients agree up to the order of the atomic sums."""
+    if case == "rgb":
+        inp = hp.inputs_from_config("cfg1", with_shs=True)
+    elif case == "features32":
+        inp = hp.make_inputs(60_000, 640, 360, 32, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
+    else:
+        inp = hp.make_inputs(20_000, 480, 272, 3, seed=6, with_shs=True, sh_degree=3, use_mask=True, bg="random")
+    # 32 channels: the f32 FMA-chain forward adds the pairs one by one in list order, so pairs with weight 0 change no bit; the
+    # default bf16x3 forward sums 16 pairs per matrix instruction, and extra zero-weight pairs regroup its partial sums (ulps)
+    f32 = True if inp.channels == 32 else None
+    on = hp.GpuRun(inp).forward(f32_blend=f32)
+    off = hp.GpuRun(inp).forward(no_cull=True, f32_blend=f32)
+    assert off.num_rendered == on.num_rendered
+    if f32:
+        a, b = hp.GpuRun(inp).forward().color, hp.GpuRun(inp).forward(no_cull=True).color
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    ids_on, _, cnt_on = on.blend_lists()
+    ids_off, qm_off, cnt_off = off.blend_lists()
+    assert cnt_off.sum() == off.num_rendered > cnt_on.sum() and np.all(qm_off == 15), "the cull should have been off"
+    ion, ioff = on.img_fields(), off.img_fields()
+    np.testing.assert_array_equal(ioff["ranges"], ion["ranges"])
+    np.testing.assert_array_equal(off.bin_fields()["point_list"], on.bin_fields()["point_list"])
+    for name, a, b in (("color", off.color, on.color), ("mask", off.out_mask, on.out_mask), ("depth", off.out_depth, on.out_depth)):
+        if a is not None:
+            np.testing.assert_array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32), err_msg=name)
+    np.testing.assert_array_equal(ioff["final_T"].view(np.uint32), ion["final_T"].view(np.uint32))
+    np.testing.assert_array_equal(ioff["n_contrib"], ion["n_contrib"])
+    W, H, C = inp.image_width, inp.image_height, inp.channels
+    dL = scenes.make_grad_image(C, H, W, seed=1)
+    dLm = None if inp.mask is None else (np.random.default_rng(8).normal(0, 1, (1, H, W)) / (W * H)).astype(np.float32)
+    g_on, g_off = on.backward(dL, dLm), off.backward(dL, dLm)
+    for k, want in g_on.items():
+        hp.assert_close(k + " (cull off vs on)", g_off[k], want, rtol=2e-4, flip_frac=max(hp.GRAD_FLIP_FRAC, 1.5 / max(1, want.size)))
