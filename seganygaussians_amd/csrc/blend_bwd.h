@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 if (!((pm >> wave) & 1u) || pos >= wave_Lt) continue;
                 if MI_ABLATE(64) continue;
                 const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
-                const float power = -0.5f * (cco.x * dx * dx + cco.z * dy * dy) - cco.y * dx * dy;
+                const float power = gauss_power(-0.5f * cco.x, -cco.y, -0.5f * cco.z, dx, dy);
                 const float G = __expf(power);
                 const float alpha = fminf(0.99f, cco.w * G);
                 const bool valid = (pos < last_contributor) && power <= 0.0f && alpha >= (1.0f / 255.0f);

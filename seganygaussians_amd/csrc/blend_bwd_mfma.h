@@ -53,8 +53,7 @@ struct BwdCfg {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // One staged record: {x, y, -a/2, -b} {-c/2, opacity, list position << 4 | quadrant mask (int bits), Gaussian id (int bits)} with the conic
-// (a, b, c) pre-scaled so that power = ((-a/2 dx) dx + (-c/2 dy) dy) + (-b dx) dy -- bit-identical to the reference
-// expression -0.5f (a dx dx + c dy dy) - b dx dy (scaling by -1/2 and -1 commutes with every rounding), two VALU fewer.
+// (a, b, c) pre-scaled to (-a/2, -b, -c/2) for gauss_power (common.h).
 struct BwdPar {
     float4 q0, q1;
 };
@@ -392,7 +391,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 const float4 p0 = *reinterpret_cast<const float4*>(par_bytes + off);
                 const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + off + 16);
                 const float dx = p0.x - pixfx, dy = p0.y - pixfy;
-                const float power = (p0.z * dx * dx + p1.x * dy * dy) + p0.w * dx * dy;
+                const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
                 const float G = __expf(power);
                 // opacity * G where the row can blend into this pixel at all, else 0; the 1/255 cut is the last test so
                 // that its compare doubles as the ballot (min(0.99, t) >= 1/255  <=>  t >= 1/255)

@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     TK(1);
     if (NS == 0) return;
     const float nTb = -T_final * bg_dot_dpixel;  // the background term of dL/dalpha is nTb / (1 - alpha)
+    const bool has_bg = ballot64(nTb != 0.f) != 0;   // wave-uniform
     const int last4 = last_contributor << 4, wave_Lt4 = wave_Lt << 4;  // compared with (position << 4 | mask)
 
     // Phi[pixel 16kq+s][j = n16] = monomial j (1, x, y, x^2, xy, y^2) about the quadrant centre, x = (s&7) - 3.5 (a
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             const float4 p0 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar));
             const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
             const float dx = p0.x - pixfx, dy = p0.y - pixfy;
-            const float power = (p0.z * dx * dx + p1.x * dy * dy) + p0.w * dx * dy;
+            const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
             const float G = __expf(power);
             // opacity * G where the row can blend into this pixel at all, else 0; the 1/255 cut is the last test
             // (min(0.99, t) >= 1/255  <=>  t >= 1/255)
@@ -349,9 +350,47 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             my_wa[rr * WROW + lane] = w;
             my_ua[rr * WROW + lane] = u;
         };
-        if constexpr (FULL) {  // straight-line code for the full chunk: the 16 rows' LDS reads overlap each other's arithmetic
+        // Four rows with ONE reciprocal (v_rcp_f32 is a quarter-rate instruction): T behind the group = T / (om0 om1 om2 om3),
+        // the T of the rows in between by multiplying back.  Only without a background term (nTb / (1 - alpha) needs each
+        // row's own reciprocal): bg = 0 is SAGA's feature training (train_contrastive_feature.py:98).
+        auto row_group4 = [&](const int r0) __attribute__((always_inline)) {
+            float tG[4], al[4], om[4];
 #pragma unroll
-            for (int rr = 0; rr < CHK; rr++) row_step(rr);
+            for (int k = 0; k < 4; k++) {
+                const int rr = r0 + k;
+                const float4 p0 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar));
+                const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
+                const float dx = p0.x - pixfx, dy = p0.y - pixfy;
+                const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
+                const float G = __expf(power);
+                const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;
+                tG[k] = t0 >= (1.0f / 255.0f) ? t0 : 0.f;
+                al[k] = fminf(0.99f, tG[k]);
+                om[k] = 1.f - al[k];
+            }
+            float Tk[4];
+            Tk[3] = T * __builtin_amdgcn_rcpf((om[0] * om[1]) * (om[2] * om[3]));
+            Tk[2] = Tk[3] * om[3];
+            Tk[1] = Tk[2] * om[2];
+            Tk[0] = Tk[1] * om[1];
+            T = Tk[3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int rr = r0 + k;
+                const float dS = my_wa[rr * WROW + lane] - Rcur;
+                Rcur = fmaf(al[k], dS, Rcur);
+                my_wa[rr * WROW + lane] = al[k] * Tk[k];
+                my_ua[rr * WROW + lane] = tG[k] * (dS * Tk[k]);
+            }
+        };
+        if constexpr (FULL) {  // straight-line code for the full chunk: the 16 rows' LDS reads overlap each other's arithmetic
+            if (has_bg) {
+#pragma unroll
+                for (int rr = 0; rr < CHK; rr++) row_step(rr);
+            } else {
+#pragma unroll
+                for (int r0 = 0; r0 < CHK; r0 += 4) row_group4(r0);
+            }
         } else {             // the wave's last chunk.  S of a padding row is 0 (zero features), so its w row is done already
 #pragma unroll
             for (int rr = 0; rr < CHK; rr++) {

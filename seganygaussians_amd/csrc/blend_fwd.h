@@ -114,8 +114,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
         // ---- A: this batch's records -> LDS; next batch's records -> registers (in flight during B and C)
         if (tid < nb) {
             s_xy[tid] = cur.xy;
-            // conic pre-scaled to (-a/2, -b, -c/2): power = ((-a/2 dx) dx + (-c/2 dy) dy) + (-b dx) dy is bit-identical to the
-            // reference's -0.5f (a dx dx + c dy dy) - b dx dy (scaling by -1/2 and -1 commutes with every rounding)
+            // conic pre-scaled to (-a/2, -b, -c/2) for gauss_power (common.h)
             s_co[tid] = make_float4(-0.5f * cur.co.x, -cur.co.y, -0.5f * cur.co.z, cur.co.w);
             s_id[tid] = cur.id;
             s_pm[tid] = cur.pm;
@@ -201,7 +200,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
                 nco = s_co[kp];
                 npm = s_pm[kp];
                 const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
-                const float power = (cco.x * dx * dx + cco.z * dy * dy) + cco.y * dx * dy;
+                const float power = gauss_power(cco.x, cco.y, cco.z, dx, dy);
                 const float t = cco.w * __expf(power);
                 const float alpha = fminf(0.99f, t);
                 const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);  // min(0.99, t) >= 1/255  <=>  t >= 1/255

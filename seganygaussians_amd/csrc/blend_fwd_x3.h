@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
                         const float4 p0 = *reinterpret_cast<const float4*>(rec_bytes + off);
                         const float4 p1 = *reinterpret_cast<const float4*>(rec_bytes + off + 16);
                         const float dx = p0.x - pixfx, dy = p0.y - pixfy;
-                        const float power = (p0.z * dx * dx + p1.x * dy * dy) + p0.w * dx * dy;
+                        const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
                         const float t = p1.y * __expf(power);
                         const float alpha = fminf(0.99f, t);
                         const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);

@@ -119,6 +119,15 @@ struct ViewParams {
     uint32_t grid_x, grid_y;
 };
 
+// Exponent of a Gaussian at offset (dx, dy) from its mean, conic pre-scaled to (ha, nb, hc) = (-a/2, -b, -c/2):
+// -0.5 (a dx^2 + c dy^2) - b dx dy (forward.cu:338, backward.cu:497) as three multiplies and three fused
+// multiply-adds.  ONE definition for every blend kernel: the forward's alpha >= 1/255 decisions are re-taken by the backward,
+// so both must round this value identically.
+__device__ __forceinline__ float gauss_power(float ha, float nb, float hc, float dx, float dy)
+{
+    return fmaf(ha * dx, dx, fmaf(hc * dy, dy, (nb * dx) * dy));
+}
+
 // ---- wave64 helpers -------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
