@@ -443,6 +443,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
                 const int ch = 16 * nb + n16;
                 if (MI_ABLATE(64)) continue;
                 if (!FULL && row >= nrows) continue;
+                if (MI_ABLATE(512)) { dL_dcolors[(size_t)gid * CR + ch] = facc[nb][r]; continue; }  // plain stores instead of atomics (wrong results)
                 if constexpr (CR == C) {
                     atomicAdd(&dL_dcolors[(size_t)gid * CR + ch], facc[nb][r]);
                 } else {
@@ -489,6 +490,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             for (int it = 0; it < 2; it++) {
                 const int row2 = 8 * it + (lane >> 3), f = lane & 7;
                 const uint32_t gid2 = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row2 * (int)sizeof(BwdPar) + 28));
+                if (MI_ABLATE(512)) { gpack[(size_t)gid2 * 8 + f] = my_mom[row2 * MROW + f]; continue; }
                 if (!MI_ABLATE(128) && (FULL || row2 < nrows)) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * MROW + f]);   // fields 6, 7 receive +0
             }
         }
