@@ -185,6 +185,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Settling, untimed and before the W warm-up steps: blocks of steps until two consecutive blocks take the same time to
+    # within 10 % (at most 8 blocks).  A freshly started process on a freshly provisioned box has been seen to run its first
+    # few hundred milliseconds of GPU work an order of magnitude slower (clocks / allocator / page cache); the W warm-up steps
+    # alone (15 ms of work) do not cover that.
+    prev_block = None
+    for _ in range(8):
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(max(5, args.warmup)):
+            step()
+        barrier()
+        tb = time.perf_counter() - tb
+        if prev_block is not None and abs(tb - prev_block) <= 0.1 * min(tb, prev_block):
+            break
+        prev_block = tb
     for _ in range(args.warmup):
         step()
     barrier()
