@@ -197,7 +197,12 @@ def main():
             step()
         barrier()
         tb = time.perf_counter() - tb
-        if prev_block is not None and abs(tb - prev_block) <= 0.1 * min(tb, prev_block):
+        settled = prev_block is not None and abs(tb - prev_block) <= 0.1 * min(tb, prev_block)
+        if dist is not None:   # every rank must run the same number of steps (each step holds a collective)
+            flag = torch.tensor([0 if settled else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            settled = int(flag.item()) == 0
+        if settled:
             break
         prev_block = tb
     for _ in range(args.warmup):
