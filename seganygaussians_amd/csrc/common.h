@@ -120,12 +120,15 @@ struct ViewParams {
 };
 
 // Exponent of a Gaussian at offset (dx, dy) from its mean, conic pre-scaled to (ha, nb, hc) = (-a/2, -b, -c/2):
-// -0.5 (a dx^2 + c dy^2) - b dx dy (forward.cu:338, backward.cu:497) as three multiplies and three fused
-// multiply-adds.  ONE definition for every blend kernel: the forward's alpha >= 1/255 decisions are re-taken by the backward,
-// so both must round this value identically.
+// ((-a/2 dx) dx + (-c/2 dy) dy) + (-b dx) dy -- bit-identical to the reference expression -0.5f (a dx dx + c dy dy) - b dx dy
+// (forward.cu:338, backward.cu:497; scaling by -1/2 and -1 commutes with every rounding), two VALU fewer.  ONE definition for
+// every blend kernel: the forward's alpha >= 1/255 decisions are re-taken by the backward, so both must round this value
+// identically.  Deliberately NOT fused: the fmaf form (two instructions fewer) was measured and bought nothing, while its
+// 1-ulp differences against an unfused reference flip pairs at the 1/255 threshold -- at full cfg3 size the norm-wise error of
+// dL_dmeans2D against the oracle went from 5.6e-7 to 5.8e-6 and the rows outside tolerance from 2.2e-4 to 1.2e-3.
 __device__ __forceinline__ float gauss_power(float ha, float nb, float hc, float dx, float dy)
 {
-    return fmaf(ha * dx, dx, fmaf(hc * dy, dy, (nb * dx) * dy));
+    return (ha * dx * dx + hc * dy * dy) + nb * dx * dy;
 }
 
 // ---- wave64 helpers -------------------------------------------------------------------------
