@@ -131,7 +131,9 @@ constexpr int RANK_BITS = 28;          // entry = depth rank | quadrant mask << 
 constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 constexpr int BIN_MAX_WG = 512;        // workgroups of the count / emit passes (rank slices)
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_TILES = 29 * 1024 - 64;  // LDS: one counter per tile + 45 KB of hand-off arrays must fit in 160 KB
+constexpr int BIN_MAX_TILES = 29 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 45 KB of hand-off
+                                               // arrays must fit in 160 KB; larger images are walked in bands of tile rows
+constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
 
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
@@ -259,10 +261,15 @@ template <bool EMIT, bool FULL = true, bool NOCULL = false>
 __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
                                                                 uint32_t* __restrict__ partial,
                                                                 const uint2* __restrict__ ranges,
-                                                                uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy)
+                                                                uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy,
+                                                                uint32_t by0, uint32_t by1)
 {
-    extern __shared__ uint32_t s_dyn[];  // [ntiles] counters / cursors, then the rect hand-off arrays
-    const int ntiles = (int)(gx * gy);
+    // One launch covers the tile rows [by0, by1) (the whole image unless it has more tiles than LDS counters: then the host
+    // walks it in bands); the LDS counters are indexed relative to the band, everything in memory by the global tile id.
+    extern __shared__ uint32_t s_dyn[];  // [band tiles] counters / cursors, then the rect hand-off arrays
+    const int ntiles = (int)(gx * (by1 - by0));
+    const int tile0 = (int)(gx * by0);
+    const int ntiles_all = (int)(gx * gy);
     uint32_t* s_cnt = s_dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* s_rw = s_dyn + ((ntiles + 3) & ~3);  // 16-byte aligned
@@ -270,8 +277,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
     float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);          // EMIT only: the owners' means ...
     float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);   // ... and conics + opacities
     uint32_t* s_queue = s_rw + 3088 + 6144;                         // ... and 128 deferred items per wave
-    uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles;
-    for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = EMIT ? ranges[t].x + my_partial[t] : 0u;
+    uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles_all + tile0;
+    for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = EMIT ? ranges[tile0 + t].x + my_partial[t] : 0u;
     __syncthreads();
     // 64-rank chunks are dealt round robin over all the waves of all the workgroups: chunk c belongs to workgroup
     // c % nwg, wave slot (c / nwg) % 16, round (c / nwg) / 16 -- the heavy (near) chunks end up in different workgroups
@@ -287,7 +294,9 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
             if (rad > 0) {
                 getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
                 if (!FULL) shrink_rect(rec.xy, rec.co, rad, rmin, rmax);  // count and emit pass alike
-                count = (rmax.x - rmin.x) * (rmax.y - rmin.y);
+                rmin.y = max(rmin.y, by0);                                  // this band's rows only
+                rmax.y = min(rmax.y, by1);
+                count = rmax.y > rmin.y ? (rmax.x - rmin.x) * (rmax.y - rmin.y) : 0u;
             }
             if (EMIT) {
                 s_xy[tid] = rec.xy;
@@ -307,7 +316,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
                 [&](uint32_t owner, uint32_t tx, uint32_t ty) {
                     if (NOCULL || tile_may_blend(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y))) return true;
                     if (FULL) {
-                        const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
+                        const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
                         entries[slot] = rank_of(owner);
                     }
                     return false;
@@ -315,14 +324,14 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
                 [&](uint32_t owner, uint32_t tx, uint32_t ty) {
                     const uint32_t qmask = NOCULL ? 15u : quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
                     if (!FULL && qmask == 0u) return;
-                    const uint32_t slot = atomicAdd(&s_cnt[ty * gx + tx], 1u);
+                    const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
                     entries[slot] = rank_of(owner) | (qmask << RANK_BITS);
                 });
         } else {
             for_each_tile_balanced<false>(
                 rw, tid, rmin, rmax, count, (uint32_t*)nullptr,
                 [&](uint32_t, uint32_t tx, uint32_t ty) {
-                    atomicAdd(&s_cnt[ty * gx + tx], 1u);
+                    atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
                     return false;
                 },
                 [](uint32_t, uint32_t, uint32_t) {});
@@ -342,11 +351,14 @@ __host__ __device__ inline int count_grid_stride(uint32_t gx) { return (int)((gx
 
 template <bool FULL>
 __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const BlendRec* __restrict__ rank_rec,
-                                                                uint32_t* __restrict__ partial, uint32_t gx, uint32_t gy)
+                                                                uint32_t* __restrict__ partial, uint32_t gx, uint32_t gy_all,
+                                                                uint32_t by0, uint32_t by1)
 {
-    extern __shared__ int s_grid[];  // [(gy + 1) * stride]
+    // tile rows [by0, by1) of the image (see bin_ranks_kernel); the difference grid covers the band only
+    extern __shared__ int s_grid[];  // [(band rows + 1) * stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int stride = count_grid_stride(gx);
+    const uint32_t gy = by1 - by0;
     const int cells = (int)(gy + 1) * stride;
     for (int c = tid; c < cells; c += BIN_THREADS) s_grid[c] = 0;
     __syncthreads();
@@ -359,9 +371,13 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
         const int rad = (int)rec.pm;
         if (rad <= 0) continue;
         uint2 rmin, rmax;
-        getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
+        getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy_all);
         if (!FULL) shrink_rect(rec.xy, rec.co, rad, rmin, rmax);
+        rmin.y = max(rmin.y, by0);
+        rmax.y = min(rmax.y, by1);
         if (rmax.x <= rmin.x || rmax.y <= rmin.y) continue;
+        rmin.y -= by0;
+        rmax.y -= by0;
         atomicAdd(&s_grid[rmin.y * stride + rmin.x], 1);
         atomicAdd(&s_grid[rmin.y * stride + rmax.x], -1);
         atomicAdd(&s_grid[rmax.y * stride + rmin.x], -1);
@@ -386,7 +402,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
     }
     __syncthreads();
     // prefix along y: one thread per column; the running sums are the per-tile counts of this slice
-    uint32_t* my_partial = partial + (size_t)blockIdx.x * (gx * gy);
+    uint32_t* my_partial = partial + (size_t)blockIdx.x * (gx * gy_all) + (size_t)gx * by0;
     for (int x = tid; x < (int)gx; x += BIN_THREADS) {
         int run = 0;
         for (int y = 0; y < (int)gy; y++) {

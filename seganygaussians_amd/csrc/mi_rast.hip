@@ -339,8 +339,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     const int ntiles = (int)(vp.grid_x * vp.grid_y);
     if (P >= (1 << RANK_BITS)) return fail(MI_RAST_ERR_INVALID, "more than 2^28 Gaussians");
     if (vp.grid_x > 2047u || vp.grid_y > 2047u) return fail(MI_RAST_ERR_INVALID, "image too large: more than 2047 tiles along one axis");
-    if (ntiles > BIN_MAX_TILES)
-        return fail(MI_RAST_ERR_INVALID, "image too large: more than 29632 tiles (e.g. 3840 x 1968 px at 16-px tiles)");
+    if (ntiles > BIN_MAX_TILES_TOTAL)
+        return fail(MI_RAST_ERR_INVALID, "image too large: more than 40896 tiles (e.g. 4096 x 2544 px at 16-px tiles)");
+    // images with more tiles than one launch of the count / emit passes has LDS counters for are walked in bands of tile rows
+    const uint32_t band_rows = std::min<uint32_t>(vp.grid_y, std::max<uint32_t>(1u, (uint32_t)BIN_MAX_TILES / vp.grid_x));
+    const uint32_t nbands = (vp.grid_y + band_rows - 1) / band_rows;
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
         HIP_TRY(hipMemsetAsync(img.num_rendered, 0, R_SLOTS * R_SLOT_STRIDE * sizeof(int), stream));
@@ -369,7 +372,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (BIN_MAX_TILES + 1) * (int)sizeof(uint32_t)));
+                                        (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         DS_NBK * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -410,27 +413,32 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     const bool nocull = (flags & MI_RAST_NO_CULL) != 0;
     const bool full = debug != 0 || nocull || (flags & MI_RAST_FULL_LISTS) != 0;
     const int nwg = bin_workgroups(P);
-    const size_t bin_lds = ((size_t)((ntiles + 3) & ~3) + 3 * 1024 + 16) * sizeof(uint32_t);
+    const size_t band_tiles = (size_t)band_rows * vp.grid_x;
+    const size_t bin_lds = ((size_t)((band_tiles + 3) & ~(size_t)3) + 3 * 1024 + 16) * sizeof(uint32_t);
     {
         // count pass over rank slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
         StageTimer t(stream, MI_STAGE_TILE_SCAN);
-        const size_t cnt_lds = (size_t)(vp.grid_y + 1) * count_grid_stride(vp.grid_x) * sizeof(int);
+        const size_t cnt_lds = (size_t)(band_rows + 1) * count_grid_stride(vp.grid_x) * sizeof(int);
+        for (uint32_t b = 0; b < nbands; b++) {
+            const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
 #ifdef MI_RAST_PROFILING
-        if (g_ablate_fwd & 4096) {  // the enumerating count pass (MI_RAST_ABLATE_FWD=4096: comparisons)
-            if (full)
-                hipLaunchKernelGGL((bin_ranks_kernel<false, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
-                                   img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
-            else
-                hipLaunchKernelGGL((bin_ranks_kernel<false, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
-                                   img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y);
-        } else
+            if (g_ablate_fwd & 4096) {  // the enumerating count pass (MI_RAST_ABLATE_FWD=4096: comparisons)
+                if (full)
+                    hipLaunchKernelGGL((bin_ranks_kernel<false, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+                                       img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y, by0, by1);
+                else
+                    hipLaunchKernelGGL((bin_ranks_kernel<false, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
+                                       img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y, by0, by1);
+                continue;
+            }
 #endif
-        if (full)
-            hipLaunchKernelGGL(bin_count_kernel<true>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
-                               img.tile_count, vp.grid_x, vp.grid_y);
-        else
-            hipLaunchKernelGGL(bin_count_kernel<false>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
-                               img.tile_count, vp.grid_x, vp.grid_y);
+            if (full)
+                hipLaunchKernelGGL(bin_count_kernel<true>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
+                                   img.tile_count, vp.grid_x, vp.grid_y, by0, by1);
+            else
+                hipLaunchKernelGGL(bin_count_kernel<false>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
+                                   img.tile_count, vp.grid_x, vp.grid_y, by0, by1);
+        }
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)ntiles + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
@@ -457,16 +465,19 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            if (nocull) {
-                hipLaunchKernelGGL((bin_ranks_kernel<true, true, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P,
-                                   geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
-            } else if (full) {
-                hipLaunchKernelGGL((bin_ranks_kernel<true, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P,
-                                   geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
-            } else {
-                HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint32_t), stream));
-                hipLaunchKernelGGL((bin_ranks_kernel<true, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds + 8 * 1024 * sizeof(uint32_t), stream, P,
-                                   geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y);
+            if (!full) HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint32_t), stream));
+            const size_t emit_lds = bin_lds + 8 * 1024 * sizeof(uint32_t);
+            for (uint32_t b = 0; b < nbands; b++) {
+                const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
+                if (nocull)
+                    hipLaunchKernelGGL((bin_ranks_kernel<true, true, true>), dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
+                                       img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
+                else if (full)
+                    hipLaunchKernelGGL((bin_ranks_kernel<true, true>), dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
+                                       img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
+                else
+                    hipLaunchKernelGGL((bin_ranks_kernel<true, false>), dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
+                                       img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
             }
         }
         STAGE_CHECK("emit ranks");

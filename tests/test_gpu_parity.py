@@ -303,3 +303,20 @@ def test_cull_is_exactly_conservative(case):
     g_on, g_off = on.backward(dL, dLm), off.backward(dL, dLm)
     for k, want in g_on.items():
         hp.assert_close(k + " (cull off vs on)", g_off[k], want, rtol=2e-4, flip_frac=max(hp.GRAD_FLIP_FRAC, 1.5 / max(1, want.size)))
+
+
+def test_4k_image_walked_in_bands():
+    """3840 x 2160 = 32 400 tiles: more than one launch of the count / emit passes has LDS counters for (29 632), so the
+    host walks the image in two bands of tile rows.  Same bit-exact integer path, same tolerances."""
+    inp = hp.make_inputs(40_000, 3840, 2160, 3, seed=21, focal=3000.0, log_scale=math.log(0.06), log_scale_std=0.7, bg="random")
+    rep, gpu, fwd = _fwd_bwd(inp)
+    assert fwd.num_rendered > 1_000_000
+    ranges = gpu.img_fields()["ranges"].reshape(-1, 2).astype(np.int64)
+    assert len(ranges) == 240 * 135 and (ranges[30000:, 1] - ranges[30000:, 0]).sum() > 0, "the second band must hold overlaps"
+    # beyond 40 896 tiles the single-workgroup range scan runs out of LDS: refused, not mis-rendered
+    import torch
+    from seganygaussians_amd import rasterizer as R
+    g = hp.GpuRun(hp.make_inputs(100, 64, 64, 3, seed=1))
+    with pytest.raises(RuntimeError, match="image too large"):
+        R.rasterize_gaussians_native(3, False, g.bg, g.means3D, g.colors, g.opac, None, g.scales, g.rots, 1.0, g.cov, g.view,
+                                     g.proj, 1.0, 1.0, 2720, 4096, g.shs, 0, g.campos, False, False)
