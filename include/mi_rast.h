@@ -50,6 +50,12 @@ extern "C" {
 #define MI_RAST_NO_CULL 4      /* testing aid: the exact-conservative cull is switched off -- every overlap of the reference's
                                   tile lists reaches the blend kernels with all four quadrant bits (implies full lists).
                                   Results must not change: images bit for bit, gradients up to the order of the atomic sums */
+#define MI_RAST_FAST_EXP 8     /* exp() of the blend kernels as v_exp_f32(x * log2e) (~5 ulp) instead of the device library's expf
+                                  (<= 1 ulp, what the reference's kernels call and the product default): +2 % views/s on cfg3, but a
+                                  few pairs that sit within a few ulp of the alpha >= 1/255 cut land on the other side of it than in
+                                  the reference (n_contrib differs on ~1e-5 of the pixels, the per-row gradient noise is ~10x the
+                                  reference's own; still inside the 1e-4 contract).  The backward MUST be given the flags of its
+                                  forward: it re-takes the same decisions */
 #define MI_RAST_F32_BLEND 2    /* 32/64-channel forward on the f32 FMA-chain kernel instead of the exactly split bf16x3
                                   matrix kernel (same alpha/T/n_contrib bit for bit; images agree to a few ulp) */
 
@@ -144,6 +150,7 @@ int mi_rast_backward(
     float* dL_dscale,            /* [P,3] */
     float* dL_drot,              /* [P,4] */
     int debug,
+    int flags,                   /* the flags of the forward call that produced the buffers (MI_RAST_FAST_EXP matters) */
     void* stream);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (CF/cuda_rasterizer/rasterizer_impl.cu:140-153).
@@ -167,7 +174,7 @@ int mi_rast_mask_forward(
 int mi_rast_mask_backward(
     int P, int R, int width, int height,
     char* geom_buffer, char* binning_buffer, char* img_buffer,
-    const float* dL_dout_mask, float* dL_dmask, int debug, void* stream);
+    const float* dL_dout_mask, float* dL_dmask, int debug, int flags, void* stream);
 
 /* ---- introspection (used by the parity tests and bench.py; not part of the reference API) ---- */
 

@@ -13,7 +13,7 @@ MI_GEOM_FIELDS = ["depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped
                   "depth_key", "index_rec", "sorted_idx", "sort_temp", "bwd_pack", "rank_rec"]
 MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed", "tile_count", "tile_cursor", "num_rendered", "blend_count", "tile_nsurv"]
 MI_BIN_FIELDS = ["entries", "scratch", "point_list", "blend_rec"]
-MI_RAST_FULL_LISTS, MI_RAST_F32_BLEND, MI_RAST_NO_CULL = 1, 2, 4   # `flags` of mi_rast_forward (include/mi_rast.h)
+MI_RAST_FULL_LISTS, MI_RAST_F32_BLEND, MI_RAST_NO_CULL, MI_RAST_FAST_EXP = 1, 2, 4, 8   # `flags` of mi_rast_forward (include/mi_rast.h)
 MI_STAGES = ["preprocess", "depth_sort", "tile_scan", "emit", "tile_sort", "blend_fwd", "blend_bwd", "geom_bwd"]
 
 EXPORTS = [
@@ -56,14 +56,14 @@ def load():
                                   vp, vp, vp, vp, vp, i, i, vp, vp, C.POINTER(i)]
     L.mi_rast_backward.restype = i
     L.mi_rast_backward.argtypes = [i, i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f,
-                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
+                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
     L.mi_rast_mark_visible.restype = i
     L.mi_rast_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
     L.mi_rast_mask_forward.restype = i
     L.mi_rast_mask_forward.argtypes = [RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, i, i, i, vp, vp, vp, vp, f,
                                        vp, vp, vp, vp, f, f, i, vp, vp, i, i, vp, C.POINTER(i)]
     L.mi_rast_mask_backward.restype = i
-    L.mi_rast_mask_backward.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, i, vp]
+    L.mi_rast_mask_backward.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, i, i, vp]
     L.mi_rast_last_error.restype = C.c_char_p
     L.mi_rast_version.restype = C.c_char_p
     L.mi_rast_supported_channels.restype = i

@@ -39,7 +39,7 @@ constexpr int SLOTS = 4;     // contributing Gaussians parked per wave before a 
 constexpr int NFIELD = 8;    // packed record: mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, mask, pad
 constexpr int ROWS = 128;    // survivor rows (features + gradient accumulators) resident in LDS at a time
 
-template <int C, bool MASKGRAD>
+template <int C, bool MASKGRAD, bool XEXP = false>
 __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
     int W, int H, const float* __restrict__ bg_color, const float* __restrict__ colors,
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 if MI_ABLATE(64) continue;
                 const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
                 const float power = gauss_power(-0.5f * cco.x, -cco.y, -0.5f * cco.z, dx, dy);
-                const float G = __expf(power);
+                const float G = gauss_exp<XEXP>(power);
                 const float alpha = fminf(0.99f, cco.w * G);
                 const bool valid = (pos < last_contributor) && power <= 0.0f && alpha >= (1.0f / 255.0f);
                 if (ballot64(valid) == 0) continue;

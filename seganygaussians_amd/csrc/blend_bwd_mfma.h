@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256, BwdCfg<C>::WAVES) blend_bwd_mfma_kernel(
                 const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + off + 16);
                 const float dx = p0.x - pixfx, dy = p0.y - pixfy;
                 const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-                const float G = __expf(power);
+                const float G = gauss_exp<false>(power);
                 // opacity * G where the row can blend into this pixel at all, else 0; the 1/255 cut is the last test so
                 // that its compare doubles as the ballot (min(0.99, t) >= 1/255  <=>  t >= 1/255)
                 const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;

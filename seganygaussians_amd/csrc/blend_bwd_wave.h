@@ -37,7 +37,7 @@ struct BwvCfg {
 
 // C: channels as the MFMA tiling sees them (16, 32, 64); CR: channels in memory (CR == C, or 3 for RGB padded to C = 16).
 // WPB: waves (quadrants) per workgroup, 1 or 4 -- the waves of a workgroup never synchronise either way.
-template <int C, int CR = C, bool MASKGRAD = false, int WPB = 1>
+template <int C, int CR = C, bool MASKGRAD = false, int WPB = 1, bool XEXP = false>
 __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ bg_color,
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
             const float dx = p0.x - pixfx, dy = p0.y - pixfy;
             const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-            const float G = __expf(power);
+            const float G = gauss_exp<XEXP>(power);
             // opacity * G where the row can blend into this pixel at all, else 0; the 1/255 cut is the last test
             // (min(0.99, t) >= 1/255  <=>  t >= 1/255)
             const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
                 const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
                 const float dx = p0.x - pixfx, dy = p0.y - pixfy;
                 const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-                const float G = __expf(power);
+                const float G = gauss_exp<XEXP>(power);
                 const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;
                 tG[k] = t0 >= (1.0f / 255.0f) ? t0 : 0.f;
                 al[k] = fminf(0.99f, tG[k]);

@@ -37,7 +37,7 @@ struct FeatStage {
     static constexpr int ROW = (CE + 3) & ~3;
 };
 
-template <int C, int EXTRA>
+template <int C, int EXTRA, bool XEXP = false>
 __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fwd_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
     int W, int H, const float* __restrict__ features, const float* __restrict__ mask, const float* __restrict__ depths,
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
                 npm = s_pm[kp];
                 const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
                 const float power = gauss_power(cco.x, cco.y, cco.z, dx, dy);
-                const float t = cco.w * __expf(power);
+                const float t = cco.w * gauss_exp<XEXP>(power);
                 const float alpha = fminf(0.99f, t);
                 const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);  // min(0.99, t) >= 1/255  <=>  t >= 1/255
                 const float test_T = T * (1 - alpha);

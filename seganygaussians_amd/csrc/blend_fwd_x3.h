@@ -50,7 +50,7 @@ __device__ __forceinline__ void split3_bf16x2(float a, float b, uint32_t& hi, ui
 }
 
 // C = 64: two 32-channel accumulator pairs (64 VGPRs), 24 MFMA per group, rows of 384 bytes: 2 workgroups per CU.
-template <int C>
+template <int C, bool XEXP = false>
 __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
     int W, int H, const float* __restrict__ features, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
                         const float4 p1 = *reinterpret_cast<const float4*>(rec_bytes + off + 16);
                         const float dx = p0.x - pixfx, dy = p0.y - pixfy;
                         const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-                        const float t = p1.y * __expf(power);
+                        const float t = p1.y * gauss_exp<XEXP>(power);
                         const float alpha = fminf(0.99f, t);
                         const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);
                         const float test_T = T * (1 - alpha);

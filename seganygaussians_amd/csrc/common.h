@@ -131,6 +131,21 @@ __device__ __forceinline__ float gauss_power(float ha, float nb, float hc, float
     return (ha * dx * dx + hc * dy * dy) + nb * dx * dy;
 }
 
+// exp() of the Gaussian exponent: ONE definition for every blend kernel (see gauss_power).  XEXP = true (product default): the
+// device library's expf (<= 1 ulp, 13 VALU instructions) -- the function the reference's kernels call.  XEXP = false
+// (MI_RAST_FAST_EXP): v_exp_f32(power * log2e), 2 instructions, ~5 ulp (the rounding of the product dominates).  The difference
+// only matters at the alpha >= 1/255 cut: measured at full cfg3 size, with the 5-ulp exp the rows of dL_dmeans2D outside
+// tolerance against the fp64 oracle are 2.2e-4 against the reference's own 1.9e-5, and ALL of that excess comes from pairs put
+// on the other side of the cut; with expf the product's statistics are the reference's and n_contrib equals the reference's on
+// every pixel.  Cost: +0.03 ms in the forward blend (ALU-bound), nothing measurable in the backward (atomic-bound): 2 % of a
+// cfg3 step.
+template <bool XEXP>
+__device__ __forceinline__ float gauss_exp(float power)
+{
+    if constexpr (XEXP) return expf(power);
+    else return __expf(power);
+}
+
 // ---- wave64 helpers -------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 

@@ -521,26 +521,51 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     return MI_RAST_OK;
 }
 
+// xexp: the device library's expf (default); false under MI_RAST_FAST_EXP (include/mi_rast.h, common.h gauss_exp)
 template <int C, int EXTRA>
 void launch_blend_fwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin,
                       const GeomPtrs& geom, const float* features, const float* mask, const float* bg,
-                      float* out_color, float* out_mask, float* out_depth)
+                      float* out_color, float* out_mask, float* out_depth, bool xexp)
 {
     const int g_ablate_fwd = ablate_env("MI_RAST_ABLATE_FWD");
-    hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                       bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
-                       img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, g_ablate_fwd);
+    if (xexp)
+        hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA, true>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+                           bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
+                           img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, g_ablate_fwd);
+    else
+        hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA, false>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+                           bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
+                           img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, g_ablate_fwd);
+}
+
+template <int C>
+void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const float* features,
+                         const float* bg, float* out_color, bool xexp)
+{
+    if (xexp)
+        hipLaunchKernelGGL((blend_fwd_x3_kernel<C, true>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
+                           img.blend_count, vp.W, vp.H, features, img.final_T, img.n_contrib, img.tile_consumed, img.tile_nsurv, bg,
+                           out_color);
+    else
+        hipLaunchKernelGGL((blend_fwd_x3_kernel<C, false>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
+                           img.blend_count, vp.W, vp.H, features, img.final_T, img.n_contrib, img.tile_consumed, img.tile_nsurv, bg,
+                           out_color);
 }
 
 template <int C, bool MASKGRAD>
 void launch_blend_bwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin,
                       const GeomPtrs& geom, const float* colors, const float* bg, const float* dL_dpix,
-                      const float* dL_dout_mask, float* dL_dcolor)
+                      const float* dL_dout_mask, float* dL_dcolor, bool xexp)
 {
     const int g_ablate = ablate_env("MI_RAST_ABLATE");
-    hipLaunchKernelGGL((blend_bwd_kernel<C, MASKGRAD>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                       bin.blend_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
-                       dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate);
+    if (xexp)
+        hipLaunchKernelGGL((blend_bwd_kernel<C, MASKGRAD, true>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+                           bin.blend_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
+                           dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate);
+    else
+        hipLaunchKernelGGL((blend_bwd_kernel<C, MASKGRAD, false>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
+                           bin.blend_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
+                           dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate);
 }
 
 }  // namespace
@@ -831,19 +856,14 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
     }
     {
         StageTimer t(stream, MI_STAGE_BLEND_FWD);
-        if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth);
-        else if (channels == 3) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
+        const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;
+        if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
+        else if (channels == 3) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
         else if (flags & MI_RAST_F32_BLEND) {  // f32 FMA-chain forward (include/mi_rast.h)
-            if (channels == 32) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
-            else launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr);
-        } else if (channels == 32)
-            hipLaunchKernelGGL(blend_fwd_x3_kernel<32>, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
-                               img.blend_count, vp.W, vp.H, feature_ptr, img.final_T, img.n_contrib, img.tile_consumed,
-                               img.tile_nsurv, background, out_color);
-        else
-            hipLaunchKernelGGL(blend_fwd_x3_kernel<64>, dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
-                               img.blend_count, vp.W, vp.H, feature_ptr, img.final_T, img.n_contrib, img.tile_consumed,
-                               img.tile_nsurv, background, out_color);
+            if (channels == 32) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
+            else launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
+        } else if (channels == 32) launch_blend_fwd_x3<32>(vp, stream, img, bin, feature_ptr, background, out_color, xexp);
+        else launch_blend_fwd_x3<64>(vp, stream, img, bin, feature_ptr, background, out_color, xexp);
     }
     STAGE_CHECK("render");
     return MI_RAST_OK;
@@ -856,10 +876,11 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
                      float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
                      const float* dL_dpix, const float* dL_dout_mask, float* dL_dmean2D, float* dL_dconic,
                      float* dL_dopacity, float* dL_dcolor, float* dL_dmask, float* dL_dmean3D, float* dL_dcov3D,
-                     float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream_)
+                     float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, int flags, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (P <= 0) return MI_RAST_OK;
+    const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;
     const int g_ablate = ablate_env("MI_RAST_ABLATE");
     (void)g_ablate;
     if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
@@ -880,15 +901,24 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
                        bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib, dL_dpix, \
                        dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
         const uint32_t nt_ = vp.grid_x * vp.grid_y;
-#define LAUNCH_BWD_WAVE_(WPB, ...)                                                                                        \
-    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB>), dim3(WPB == 1 ? ((nt_ + 7u) / 8u) * 32u : nt_), dim3(64 * WPB), 0, \
+#define LAUNCH_BWD_WAVE_(WPB, XE, ...)                                                                                    \
+    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE>), dim3(WPB == 1 ? ((nt_ + 7u) / 8u) * 32u : nt_), dim3(64 * WPB), 0, \
                        stream, img.ranges, bin.blend_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, background, color_ptr, \
                        img.final_T, img.n_contrib, dL_dpix, dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
+#ifdef MI_RAST_PROFILING
 #define LAUNCH_BWD_WAVE(...)                                                    \
     do {                                                                        \
-        if (g_ablate & 4096) LAUNCH_BWD_WAVE_(4, __VA_ARGS__);                  \
-        else LAUNCH_BWD_WAVE_(1, __VA_ARGS__);                                  \
+        if (xexp) LAUNCH_BWD_WAVE_(1, true, __VA_ARGS__);                       \
+        else if (g_ablate & 4096) LAUNCH_BWD_WAVE_(4, false, __VA_ARGS__);      \
+        else LAUNCH_BWD_WAVE_(1, false, __VA_ARGS__);                           \
     } while (0)
+#else
+#define LAUNCH_BWD_WAVE(...)                                                    \
+    do {                                                                        \
+        if (xexp) LAUNCH_BWD_WAVE_(1, true, __VA_ARGS__);                       \
+        else LAUNCH_BWD_WAVE_(1, false, __VA_ARGS__);                           \
+    } while (0)
+#endif
 #ifdef MI_RAST_PROFILING
         if (g_ablate & 2048) {  // the tile-batched MFMA kernel (blend_bwd_mfma.h), for comparisons
             if (maskgrad) LAUNCH_BWD_MFMA(16, 3, true);
@@ -896,10 +926,10 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
             else if (channels == 32) LAUNCH_BWD_MFMA(32);
             else LAUNCH_BWD_MFMA(64);
         } else if (g_ablate & 1024) {  // the VALU kernels (timing comparisons)
-            if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor);
-            else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
-            else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
-            else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor);
+            if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor, xexp);
+            else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor, xexp);
+            else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor, xexp);
+            else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor, xexp);
         } else
 #endif
         if (maskgrad) LAUNCH_BWD_WAVE(16, 3, true);
@@ -981,14 +1011,14 @@ int mi_rast_mask_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (rc) return rc;
     {
         StageTimer t(stream, MI_STAGE_BLEND_FWD);
-        launch_blend_fwd<0, 1>(vp, stream, img, bin, geom, nullptr, mask, nullptr, nullptr, out_mask, nullptr);
+        launch_blend_fwd<0, 1>(vp, stream, img, bin, geom, nullptr, mask, nullptr, nullptr, out_mask, nullptr, (flags & MI_RAST_FAST_EXP) == 0);
     }
     STAGE_CHECK("render_mask");
     return MI_RAST_OK;
 }
 
 int mi_rast_mask_backward(int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
-                          char* img_buffer, const float* dL_dout_mask, float* dL_dmask, int debug, void* stream_)
+                          char* img_buffer, const float* dL_dout_mask, float* dL_dmask, int debug, int flags, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (P <= 0) return MI_RAST_OK;
@@ -1004,7 +1034,7 @@ int mi_rast_mask_backward(int P, int R, int width, int height, char* geom_buffer
     {
         StageTimer t(stream, MI_STAGE_BLEND_BWD);
         HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float), stream));
-        launch_blend_bwd<0, true>(vp, stream, img, bin, geom, nullptr, nullptr, nullptr, dL_dout_mask, nullptr);
+        launch_blend_bwd<0, true>(vp, stream, img, bin, geom, nullptr, nullptr, nullptr, dL_dout_mask, nullptr, (flags & MI_RAST_FAST_EXP) == 0);
         hipLaunchKernelGGL(unpack_mask_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom.bwd_pack, dL_dmask);
     }
     STAGE_CHECK("render_mask backward");

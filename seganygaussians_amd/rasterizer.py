@@ -108,11 +108,15 @@ _opts = _CallOptions()
 
 
 @contextlib.contextmanager
-def forward_flags(full_lists=None, f32_blend=None, no_cull=None):
+def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None):
     """Within the block, forwards of this thread run with the given modes: `full_lists` materialises the reference's
-    point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels, `no_cull` switches the exact-conservative cull off (testing aid)."""
+    point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels, `no_cull` switches the exact-conservative cull off (testing aid), `fast_exp` evaluates exp() as
+    v_exp_f32(x * log2e) instead of the device library's expf the reference's kernels call (+2 % views/s, ~5 ulp: a few
+    alpha >= 1/255 decisions differ from the reference's).  The flags of a
+    forward are remembered with its buffers and handed to its backward."""
     prev = _opts.flags
-    for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend), (_lib.MI_RAST_NO_CULL, no_cull)):
+    for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend), (_lib.MI_RAST_NO_CULL, no_cull),
+                   (_lib.MI_RAST_FAST_EXP, fast_exp)):
         if v is not None:
             _opts.flags = (_opts.flags | bit) if v else (_opts.flags & ~bit)
     try:
@@ -165,6 +169,7 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
                 int(_opts.flags), None if ready is None else C.c_void_p(ready.cuda_event), _stream_ptr(dev),
                 C.byref(n))
         del ready
+        geom.tensor.mi_flags = int(_opts.flags)   # the backward re-takes the forward's decisions: it needs the same flags
         _check(rc)
         rendered = n.value
     else:
@@ -185,10 +190,16 @@ def set_features_ready_event(event) -> None:
     _opts.features_ready = event
 
 
+def _flags_of(geomBuffer, flags):
+    """The MI_RAST_* flags a backward must run with are those of the forward that filled `geomBuffer`: given explicitly
+    (the autograd Functions keep them in ctx), else the note the native forward left on its tensor, else none."""
+    return flags if flags is not None else getattr(geomBuffer, "mi_flags", 0)
+
+
 def rasterize_gaussians_backward_native(channels, with_mask_depth, background, means3D, radii, colors, scales,
                                         rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
                                         tan_fovy, dL_dout_color, dL_dout_mask, sh, degree, campos, geomBuffer, R,
-                                        binningBuffer, imageBuffer, debug):
+                                        binningBuffer, imageBuffer, debug, flags=None):
     """RasterizeGaussiansBackwardCUDA (CF/rasterize_points.cu:117-196; DEPTH/rasterize_points.cu)."""
     L = _lib.load()
     P = means3D.size(0)
@@ -243,7 +254,7 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
                 dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
                 dL_dmask.data_ptr() if with_mask_depth else None, dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M > 0 else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(),
-                int(bool(debug)), _stream_ptr(dev))
+                int(bool(debug)), int(_flags_of(geomBuffer, flags)), _stream_ptr(dev))
         _check(rc)
     if with_mask_depth:
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmask, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
@@ -293,12 +304,13 @@ def rasterize_mask_gaussians_native(means3D, opacity, mask, scales, rotations, s
                 int(_opts.flags), _stream_ptr(dev), C.byref(n))
         _check(rc)
         rendered = n.value
+        geom.tensor.mi_flags = int(_opts.flags)
     else:
         out_mask = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
     return rendered, out_mask, radii, geom.tensor, binning.tensor, img.tensor
 
 
-def rasterize_mask_gaussians_backward_native(means3D, dL_dout_mask, geomBuffer, R, binningBuffer, imageBuffer, debug):
+def rasterize_mask_gaussians_backward_native(means3D, dL_dout_mask, geomBuffer, R, binningBuffer, imageBuffer, debug, flags=None):
     L = _lib.load()
     P = means3D.size(0)
     H, W = dL_dout_mask.size(-2), dL_dout_mask.size(-1)
@@ -309,7 +321,8 @@ def rasterize_mask_gaussians_backward_native(means3D, dL_dout_mask, geomBuffer, 
         with torch.cuda.device(dev):
             rc = L.mi_rast_mask_backward(P, int(R), W, H, geomBuffer.data_ptr(), binningBuffer.data_ptr(),
                                          imageBuffer.data_ptr(), _dev_ptr(d_c, "dL_dout_mask", dev),
-                                         dL_dmask.data_ptr(), int(bool(debug)), _stream_ptr(dev))
+                                         dL_dmask.data_ptr(), int(bool(debug)), int(_flags_of(geomBuffer, flags)),
+                                         _stream_ptr(dev))
         _check(rc)
     return dL_dmask
 
@@ -351,6 +364,7 @@ def _make_plain(channels):
                 num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = call()
             ctx.raster_settings = rs
             ctx.num_rendered = num_rendered
+            ctx.mi_flags = getattr(geomBuffer, "mi_flags", 0)
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
@@ -369,7 +383,8 @@ def _make_plain(channels):
             def call():
                 (bg, m3, rad, col, sc, rot, smod, cov, vm, pm, tx, ty, gout, sh_, deg, cp, gb, nr, bb, ib, dbg) = args
                 return rasterize_gaussians_backward_native(channels, False, bg, m3, rad, col, sc, rot, smod, cov, vm,
-                                                           pm, tx, ty, gout, None, sh_, deg, cp, gb, nr, bb, ib, dbg)
+                                                           pm, tx, ty, gout, None, sh_, deg, cp, gb, nr, bb, ib, dbg,
+                                                           flags=ctx.mi_flags)
 
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
@@ -458,6 +473,7 @@ def _make_depth():
             ctx.mask_shape = mask.shape
             ctx.raster_settings = rs
             ctx.num_rendered = num_rendered
+            ctx.mi_flags = getattr(geomBuffer, "mi_flags", 0)
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
@@ -477,7 +493,8 @@ def _make_depth():
                 (bg, m3, rad, col, sc, rot, smod, cov, vm, pm, tx, ty, gout, gmask, sh_, deg, cp, gb, nr, bb, ib,
                  dbg) = args
                 return rasterize_gaussians_backward_native(channels, True, bg, m3, rad, col, sc, rot, smod, cov, vm,
-                                                           pm, tx, ty, gout, gmask, sh_, deg, cp, gb, nr, bb, ib, dbg)
+                                                           pm, tx, ty, gout, gmask, sh_, deg, cp, gb, nr, bb, ib, dbg,
+                                                           flags=ctx.mi_flags)
 
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
@@ -508,6 +525,7 @@ def _make_depth():
             ctx.raster_settings = rs
             ctx.num_rendered = num_rendered
             ctx.mask_shape = mask.shape
+            ctx.mi_flags = getattr(geomBuffer, "mi_flags", 0)
             ctx.save_for_backward(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, radii, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
@@ -519,7 +537,8 @@ def _make_depth():
             (means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, radii, geomBuffer, binningBuffer,
              imgBuffer) = ctx.saved_tensors
             grad_mask = rasterize_mask_gaussians_backward_native(means3D, grad_out_mask, geomBuffer, ctx.num_rendered,
-                                                                 binningBuffer, imgBuffer, rs.debug).view(ctx.mask_shape)
+                                                                 binningBuffer, imgBuffer, rs.debug,
+                                                                 flags=ctx.mi_flags).view(ctx.mask_shape)
             # only the mask receives a real gradient; the reference hands ZEROS (not None) to every other input
             # (DEPTH/.../__init__.py:278-290) -- kept, but shaped like the inputs so autograd accepts them.
             z = [torch.zeros_like(t) if need else None for t, need in

@@ -49,11 +49,11 @@ def _pin_oracle(inp, variant=None):
     return rep, ref, rf, rb
 
 
-def _product_vs_ref(inp, variant=None, lean=True):
+def _product_vs_ref(inp, variant=None, lean=True, fast_exp=None):
     """product (full-list mode for the integer path) vs reference; then the product default (lean lists) vs full."""
     ref = sr.RefRun(inp, variant)
     rf = ref.forward()
-    gpu = hp.GpuRun(inp).forward()
+    gpu = hp.GpuRun(inp).forward(fast_exp=fast_exp)
     hp.compare_integer_path(gpu, rf)
     rep = hp.compare_float_forward(gpu, rf)
     dL, dLm = _dL(inp)
@@ -62,7 +62,7 @@ def _product_vs_ref(inp, variant=None, lean=True):
     rep.update(hp.compare_gradients(grads, rb))
     rep["stats"] = hp.error_stats(grads, rb)
     if lean:
-        hp.compare_lean_with_full(inp, gpu, dL, dLm, grads)
+        hp.compare_lean_with_full(inp, gpu, dL, dLm, grads, fast_exp=fast_exp)
     return rep, gpu, ref, rf, rb, grads
 
 
@@ -196,21 +196,60 @@ def _check_stats(stats, ref_stats, what, row_floor=1e-3, norm_floor=1e-4):
         assert s["row_frac"] <= max(row_floor, 3 * (r["row_frac"] if r else 0)), (what, k, s, r)
 
 
-def test_full_size_cfg3_product_vs_ref_and_oracle():
-    """BASELINE config 3 at FULL size: product vs reference (integer path bit-exact in full-list mode; image, final_T,
-    all gradients; lean == full), with norm-wise and per-row (median floor) error statistics measured against the
-    fp64-accumulating oracle for BOTH the product and the reference."""
+_CFG3_ORACLE = {}
+
+
+def _cfg3_oracle(inp, dL):
+    """fp64-accumulating oracle on full cfg3 (tens of seconds of CPU): computed once for the tests below."""
+    if "b" not in _CFG3_ORACLE:
+        of = so.forward(inp)
+        _CFG3_ORACLE["f"], _CFG3_ORACLE["b"] = of, so.backward(inp, of, dL)
+    return _CFG3_ORACLE["f"], _CFG3_ORACLE["b"]
+
+
+def _cfg3_stats(fast_exp):
     inp = hp.inputs_from_config("cfg3")
-    rep, gpu, ref, rf, rb, grads = _product_vs_ref(inp)
-    of = so.forward(inp)
+    rep, gpu, ref, rf, rb, grads = _product_vs_ref(inp, fast_exp=fast_exp)
     dL, _ = _dL(inp)
-    ob = so.backward(inp, of, dL)
+    of, ob = _cfg3_oracle(inp, dL)
     mine = hp.error_stats(grads, ob)
     theirs = hp.error_stats(hp.grads_as_dict(rb), ob)
-    _check_stats(mine, theirs, "cfg3 product-vs-oracle")
     img_norm = hp.norm_error(gpu.color.cpu().numpy(), of.color)
     ref_norm = hp.norm_error(rf.color, of.color)
-    print(f"cfg3 image norm-wise error: product {img_norm:.2e}, reference {ref_norm:.2e}")
+    print(f"cfg3 image norm-wise error against the fp64 oracle: product {img_norm:.2e}, reference {ref_norm:.2e}")
+    nc_mismatch = float((gpu.img_fields()["n_contrib"] != rf.state.field(so.F_N_CONTRIB)).mean())
+    print(f"cfg3: n_contrib differs from the reference on {nc_mismatch:.2e} of the pixels")
+    return mine, theirs, img_norm, ref_norm, nc_mismatch
+
+
+def test_full_size_cfg3_product_vs_ref_and_oracle():
+    """BASELINE config 3 at FULL size, product default: product vs reference (integer path bit-exact in full-list mode;
+    image, final_T, all gradients; lean == full), with norm-wise and per-row (median floor) error statistics measured
+    against the fp64-accumulating oracle for BOTH the product and the reference.  The product calls the device library's
+    expf like the reference's kernels (FEAT/forward.cu:343, backward.cu:483), so every alpha >= 1/255 and T < 1e-4
+    decision falls as in the reference: the per-pixel contributor counts are EQUAL on every pixel, and the product's
+    gradient errors are those of the reference itself (two different orders of f32 atomic sums) -- asserted at 2x."""
+    mine, theirs, img_norm, ref_norm, nc_mismatch = _cfg3_stats(fast_exp=None)
+    bad = []
+    for k, s in mine.items():
+        r = theirs[k]
+        print(f"cfg3 {k}: norm {s['norm']:.2e} rows outside {s['row_frac']:.2e} worst {s['row_worst']:.1f}"
+              f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}")
+        assert not s["zero_rows_touched"]
+        if not (s["norm"] <= 2 * r["norm"] + 1e-7 and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
+            bad.append((k, s, r))
+    assert not bad, bad
+    assert nc_mismatch == 0.0
+    assert img_norm <= max(1e-6, 3 * ref_norm)
+
+
+def test_full_size_cfg3_fast_exp_mode():
+    """MI_RAST_FAST_EXP (include/mi_rast.h): v_exp_f32(x * log2e), ~5 ulp.  A handful of pairs within a few ulp of the
+    alpha >= 1/255 cut change side; still inside the contract (1e-4 element-wise, checked by _product_vs_ref) and within
+    3x the reference's own norm-wise / per-row noise (floors 1e-4 / 1e-3)."""
+    mine, theirs, img_norm, ref_norm, nc_mismatch = _cfg3_stats(fast_exp=True)
+    _check_stats(mine, theirs, "cfg3 fast-exp product-vs-oracle")
+    assert nc_mismatch < 1e-4
     assert img_norm <= max(1e-5, 3 * ref_norm)
 
 
