@@ -260,8 +260,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 const float dx = cxy.x - pixfx, dy = cxy.y - pixfy;
                 const float power = gauss_power(-0.5f * cco.x, -cco.y, -0.5f * cco.z, dx, dy);
                 const float G = gauss_exp<XEXP>(power);
-                const float alpha = fminf(0.99f, cco.w * G);
-                const bool valid = (pos < last_contributor) && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                const float t = cco.w * G;
+                const float alpha = fminf(0.99f, t);
+                // the forward's test, on t (min(0.99, t) >= 1/255 <=> t >= 1/255; false for a NaN t like there)
+                const bool valid = (pos < last_contributor) && power <= 0.0f && t >= (1.0f / 255.0f);
                 if (ballot64(valid) == 0) continue;
                 if MI_ABLATE(16) continue;
 

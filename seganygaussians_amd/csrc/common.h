@@ -132,18 +132,36 @@ __device__ __forceinline__ float gauss_power(float ha, float nb, float hc, float
 }
 
 // exp() of the Gaussian exponent: ONE definition for every blend kernel (see gauss_power).  XEXP = true (product default): the
-// device library's expf (<= 1 ulp, 13 VALU instructions) -- the function the reference's kernels call.  XEXP = false
+// device library's expf (<= 1 ulp, 13 VALU instructions; 10 as restated below) -- the function the reference's kernels call.  XEXP = false
 // (MI_RAST_FAST_EXP): v_exp_f32(power * log2e), 2 instructions, ~5 ulp (the rounding of the product dominates).  The difference
 // only matters at the alpha >= 1/255 cut: measured at full cfg3 size, with the 5-ulp exp the rows of dL_dmeans2D outside
 // tolerance against the fp64 oracle are 2.2e-4 against the reference's own 1.9e-5, and ALL of that excess comes from pairs put
 // on the other side of the cut; with expf the product's statistics are the reference's and n_contrib equals the reference's on
 // every pixel.  Cost: +0.03 ms in the forward blend (ALU-bound), nothing measurable in the backward (atomic-bound): 2 % of a
 // cfg3 step.
+//
+// The expf form is the device library's algorithm (ocml expf, f32 with denormals, as hipcc compiles it for gfx950) restated
+// with ONE clamp in place of its two range selects (0 below -103.28, inf above 88.72; two v_cmp + two v_cndmask):
+// exp(x) = ldexp(exp2((ph - e) + pl), e) with ph + pl = x log2(e) in two-term precision and e = rint(ph), on max(x, -104).
+// For every f32 x in [-103.28, 0] the result is bit-identical to expf(x); below that, where expf gives exactly 0, it is 0 or
+// the smallest denormal (tools/expf_check.hip runs all 2^32 inputs; tests/test_gpu_parity.py::test_lean_expf_is_the_device_
+// expf).  The clamp is needed: without it a hugely negative exponent (a degenerate conic) with a positive rounding residual
+// pl ends in ldexp(inf, INT_MIN) = inf.  Where the two differ the blend kernels do not use the value: power > 0 and NaN are
+// rejected by their own `power <= 0` test (forward.cu:339), and opacity times a denormal fails the >= 1/255 test like
+// opacity times 0.
 template <bool XEXP>
 __device__ __forceinline__ float gauss_exp(float power)
 {
-    if constexpr (XEXP) return expf(power);
-    else return __expf(power);
+    if constexpr (XEXP) {
+        const float x = __builtin_fmaxf(power, -104.0f);
+        const float ph = x * 0x1.715476p+0f;
+        float pl = __builtin_fmaf(x, 0x1.715476p+0f, -ph);
+        pl = __builtin_fmaf(x, 0x1.4ae0bep-26f, pl);
+        const float e = __builtin_rintf(ph);
+        return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f((ph - e) + pl), (int)e);
+    } else {
+        return __expf(power);
+    }
 }
 
 // ---- wave64 helpers -------------------------------------------------------------------------

@@ -320,3 +320,18 @@ def test_4k_image_walked_in_bands():
     with pytest.raises(RuntimeError, match="image too large"):
         R.rasterize_gaussians_native(3, False, g.bg, g.means3D, g.colors, g.opac, None, g.scales, g.rots, 1.0, g.cov, g.view,
                                      g.proj, 1.0, 1.0, 2720, 4096, g.shs, 0, g.campos, False, False)
+
+
+def test_lean_expf_is_the_device_expf(tmp_path):
+    """gauss_exp<true> (csrc/common.h) is the device library's expf restated with a clamp instead of its two range selects:
+    tools/expf_check.hip compares the two on ALL 2^32 f32 inputs -- bit-identical on [-103.28, 0], and 0 or the smallest
+    denormal where expf underflows to 0 (the blend kernels' >= 1/255 test cannot tell those apart)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "expf_check")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize",
+                    "-Wno-unused-result", "-o", exe, os.path.join(root, "tools", "expf_check.hip")], check=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0 and r.stdout.startswith("mismatches 0 0 "), r.stdout + r.stderr
