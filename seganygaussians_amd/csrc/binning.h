@@ -48,14 +48,9 @@ struct RectWork {
     uint32_t* wsum;    // LDS [16]
 };
 
-// Contains workgroup barriers: call from all 1024 threads.
-// f1(owner_thread, tile_x, tile_y) handles an item or returns true to DEFER it; deferred items collect in a per-wave
-// LDS queue (ballot-prefix positions, wave-synchronous: no barrier) and are handed to f2 sixty-four at a time, i.e.
-// on dense lanes.  With DEFER = false, f1's return value is ignored and f2 is never called.
-template <bool DEFER, typename F1, typename F2>
-__device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int tid, uint2 rmin, uint2 rmax, uint32_t count,
-                                                       uint32_t* wave_queue /* LDS [128] per wave when DEFER */, F1&& f1,
-                                                       F2&& f2)
+// Contains workgroup barriers: call from all 1024 threads.  f(owner_thread, tile_x, tile_y) handles one item.
+template <typename F>
+__device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int tid, uint2 rmin, uint2 rmax, uint32_t count, F&& f)
 {
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t incl = wave_inclusive_scan(count, lane);
@@ -73,53 +68,21 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
     rw.rx[tid] = rmin.x | ((rmax.x - rmin.x) << 16);
     rw.ry[tid] = rmin.y;
     __syncthreads();
-    uint32_t queued = 0;  // wave-uniform
-    const uint32_t wave_items_end = total;
-    for (uint32_t k0 = (uint32_t)(tid - lane); k0 < wave_items_end; k0 += 1024) {  // wave-uniform trip count
-        const uint32_t k = k0 + (uint32_t)lane;
-        bool defer = false;
-        uint32_t item = 0;
-        if (k < total) {
-            // first thread o with prefix[o] > k
-            int lo = 0;
+    for (uint32_t k = (uint32_t)tid; k < total; k += 1024) {
+        // first thread o with prefix[o] > k
+        int lo = 0;
 #pragma unroll
-            for (int step = 512; step >= 1; step >>= 1)
-                if (rw.prefix[lo + step - 1] <= k) lo += step;
-            const uint32_t packed = rw.rx[lo];
-            const uint32_t w = packed >> 16, x0 = packed & 0xFFFFu, y0 = rw.ry[lo];
-            const uint32_t prev = lo == 0 ? 0u : rw.prefix[lo - 1];
-            const uint32_t i = k - prev;
-            // row = i / w without an integer divide: (i + 0.5) / w is never within float error of an integer
-            // boundary for i < 2^14 * w (a Gaussian covers at most grid_x * grid_y tiles)
-            const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w));
-            const uint32_t col = i - row * w;
-            const uint32_t tx = x0 + col, ty = y0 + row;
-            defer = f1((uint32_t)lo, tx, ty);
-            item = (uint32_t)lo | (tx << 10) | (ty << 21);
-        }
-        if (!DEFER) continue;
-        const uint64_t bal = ballot64(defer);
-        if (bal != 0) {
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (defer) wave_queue[queued + below] = item;
-            queued += (uint32_t)__builtin_popcountll(bal);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (queued >= 64u) {
-                const uint32_t e = wave_queue[lane];
-                const uint32_t spill = wave_queue[64 + lane];  // entries 64 .. queued-1 move down afterwards
-                f2(e & 0x3FFu, (e >> 10) & 0x7FFu, e >> 21);
-                queued -= 64u;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if ((uint32_t)lane < queued) wave_queue[lane] = spill;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            }
-        }
-    }
-    if (DEFER && queued != 0) {
-        if ((uint32_t)lane < queued) {
-            const uint32_t e = wave_queue[lane];
-            f2(e & 0x3FFu, (e >> 10) & 0x7FFu, e >> 21);
-        }
+        for (int step = 512; step >= 1; step >>= 1)
+            if (rw.prefix[lo + step - 1] <= k) lo += step;
+        const uint32_t packed = rw.rx[lo];
+        const uint32_t w = packed >> 16, x0 = packed & 0xFFFFu, y0 = rw.ry[lo];
+        const uint32_t prev = lo == 0 ? 0u : rw.prefix[lo - 1];
+        const uint32_t i = k - prev;
+        // row = i / w without an integer divide: (i + 0.5) / w is never within float error of an integer
+        // boundary for i < 2^14 * w (a Gaussian covers at most grid_x * grid_y tiles)
+        const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+        const uint32_t col = i - row * w;
+        f((uint32_t)lo, x0 + col, y0 + row);
     }
     __syncthreads();  // LDS hand-off arrays are reused by the next call
 }
@@ -129,9 +92,10 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
 // {0,0} for empty tiles as left by the reference's cudaMemset), R and the longest list.
 constexpr int RANK_BITS = 28;          // entry = depth rank | quadrant mask << 28
 constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
-constexpr int BIN_MAX_WG = 512;        // workgroups of the count / emit passes (rank slices)
+constexpr int BIN_MAX_WG = 256;        // workgroups of the count / emit passes (rank slices): one per CU, all resident at once
+                                       // (measured 512 / 256 / 128 / 64 slices on cfg3: count + emit 0.167 / 0.146 / 0.199 / 0.349 ms)
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_TILES = 29 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 45 KB of hand-off
+constexpr int BIN_MAX_TILES = 26 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 57 KB of hand-off
                                                // arrays must fit in 160 KB; larger images are walked in bands of tile rows
 constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
 
@@ -250,23 +214,21 @@ inline int bin_workgroups(int P)
     return blocks < 1 ? 1 : (blocks > BIN_MAX_WG ? BIN_MAX_WG : blocks);
 }
 
-// FULL (emit pass): every overlap is stored, culled ones with mask 0 -- the per-tile sort then reproduces the reference's
-// point_list.  !FULL ("lean", the default of the product path): `entries` was zero-filled and only the overlaps that
-// pass the cull are stored (a third of them; non-zero because their mask is), at the front of the slice's share of
-// the tile's segment; the per-tile sort drops the zeros and never materialises point_list.  Both passes then walk
-// only the part of each rect that the cull can keep (shrink_rect): counts, ranges and segments are upper bounds of
-// the lean lists, not the reference's.
-// NOCULL (testing aid, MI_RAST_NO_CULL): every overlap of the reference's lists is kept with all four quadrant bits.
-template <bool EMIT, bool FULL = true, bool NOCULL = false>
+// Emit pass of the FULL lists (the reference's `debug` flag, MI_RAST_FULL_LISTS: parity tests): every overlap of the
+// reference's rects is stored, with the quadrant mask the lean lists would give it (cull.h: span_tile_mask; 0 = culled) in
+// the top 4 bits -- the per-tile sort then reproduces the reference's point_list and gathers a blend record only for entries
+// that blend.  NOCULL (testing aid, MI_RAST_NO_CULL): every overlap is kept with all four quadrant bits.
+// The product default does not come here: bin_spans_kernel below.
+template <bool NOCULL = false>
 __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
-                                                                uint32_t* __restrict__ partial,
+                                                                const uint32_t* __restrict__ partial,
                                                                 const uint2* __restrict__ ranges,
                                                                 uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy,
                                                                 uint32_t by0, uint32_t by1)
 {
     // One launch covers the tile rows [by0, by1) (the whole image unless it has more tiles than LDS counters: then the host
-    // walks it in bands); the LDS counters are indexed relative to the band, everything in memory by the global tile id.
-    extern __shared__ uint32_t s_dyn[];  // [band tiles] counters / cursors, then the rect hand-off arrays
+    // walks it in bands); the LDS cursors are indexed relative to the band, everything in memory by the global tile id.
+    extern __shared__ uint32_t s_dyn[];  // [band tiles] cursors, then the rect hand-off arrays
     const int ntiles = (int)(gx * (by1 - by0));
     const int tile0 = (int)(gx * by0);
     const int ntiles_all = (int)(gx * gy);
@@ -274,11 +236,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* s_rw = s_dyn + ((ntiles + 3) & ~3);  // 16-byte aligned
     RectWork rw{s_rw, s_rw + 1024, s_rw + 2048, s_rw + 3072};
-    float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);          // EMIT only: the owners' means ...
-    float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);   // ... and conics + opacities
-    uint32_t* s_queue = s_rw + 3088 + 6144;                         // ... and 128 deferred items per wave
-    uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles_all + tile0;
-    for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = EMIT ? ranges[tile0 + t].x + my_partial[t] : 0u;
+    float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);          // the owners' means ...
+    float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);   // ... conics + opacities ...
+    uint32_t* s_rad = s_rw + 3088 + 6144;                           // ... and radii
+    const uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles_all + tile0;
+    for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
     __syncthreads();
     // 64-rank chunks are dealt round robin over all the waves of all the workgroups: chunk c belongs to workgroup
     // c % nwg, wave slot (c / nwg) % 16, round (c / nwg) / 16 -- the heavy (near) chunks end up in different workgroups
@@ -293,63 +255,30 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
             const int rad = (int)rec.pm;
             if (rad > 0) {
                 getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
-                if (!FULL) shrink_rect(rec.xy, rec.co, rad, rmin, rmax);  // count and emit pass alike
-                rmin.y = max(rmin.y, by0);                                  // this band's rows only
+                rmin.y = max(rmin.y, by0);  // this band's rows only
                 rmax.y = min(rmax.y, by1);
                 count = rmax.y > rmin.y ? (rmax.x - rmin.x) * (rmax.y - rmin.y) : 0u;
             }
-            if (EMIT) {
-                s_xy[tid] = rec.xy;
-                s_co[tid] = rec.co;
-            }
+            s_xy[tid] = rec.xy;
+            s_co[tid] = rec.co;
+            s_rad[tid] = rec.pm;
         }
-        auto rank_of = [&](uint32_t owner) {
-            return (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
-        };
-        if (EMIT) {
-            // The exact-conservative cull (cull.h) is evaluated here, where the record is at hand, and its quadrant mask
-            // rides in the top 4 bits of the entry: the per-tile sort then gathers a record only for entries that blend.
-            // The whole-tile test runs on every overlap (two thirds end there with mask 0); the four quadrant tests of
-            // the rest run on dense lanes, 64 deferred overlaps at a time.
-            for_each_tile_balanced<true>(
-                rw, tid, rmin, rmax, count, s_queue + wave * 128,
-                [&](uint32_t owner, uint32_t tx, uint32_t ty) {
-                    if (NOCULL || tile_may_blend(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y))) return true;
-                    if (FULL) {
-                        const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
-                        entries[slot] = rank_of(owner);
-                    }
-                    return false;
-                },
-                [&](uint32_t owner, uint32_t tx, uint32_t ty) {
-                    const uint32_t qmask = NOCULL ? 15u : quadrant_mask(s_xy[owner], s_co[owner], (float)(tx * TILE_X), (float)(ty * TILE_Y));
-                    if (!FULL && qmask == 0u) return;
-                    const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
-                    entries[slot] = rank_of(owner) | (qmask << RANK_BITS);
-                });
-        } else {
-            for_each_tile_balanced<false>(
-                rw, tid, rmin, rmax, count, (uint32_t*)nullptr,
-                [&](uint32_t, uint32_t tx, uint32_t ty) {
-                    atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
-                    return false;
-                },
-                [](uint32_t, uint32_t, uint32_t) {});
-        }
-    }
-    if (!EMIT) {
-        __syncthreads();
-        for (int t = tid; t < ntiles; t += BIN_THREADS) my_partial[t] = s_cnt[t];
+        for_each_tile_balanced(rw, tid, rmin, rmax, count, [&](uint32_t owner, uint32_t tx, uint32_t ty) {
+            const uint32_t qmask = NOCULL ? 15u : span_tile_mask(s_xy[owner], s_co[owner], (int)s_rad[owner], tx, ty, gx, gy);
+            const uint32_t rank = (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
+            const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
+            entries[slot] = rank | (qmask << RANK_BITS);
+        });
     }
 }
 
 // Count pass without enumerating the overlaps: every rect adds +1 / -1 / -1 / +1 at its four corners of a
 // (gy + 1) x (gx + 1) difference grid in LDS (four LDS atomics per Gaussian instead of one per covered tile plus a
 // ten-step owner search), and a 2-D prefix sum of the grid is the number of rects covering each tile -- exactly what
-// the enumeration counts.  Same slices (rank chunks dealt round robin) and the same rects as the emit pass.
+// an enumeration would count.  Same slices (rank chunks dealt round robin) and the same rects as bin_ranks_kernel: the count
+// pass of the FULL lists.
 __host__ __device__ inline int count_grid_stride(uint32_t gx) { return (int)((gx + 1) | 1u); }  // odd row stride: column walks spread over the banks
 
-template <bool FULL>
 __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const BlendRec* __restrict__ rank_rec,
                                                                 uint32_t* __restrict__ partial, uint32_t gx, uint32_t gy_all,
                                                                 uint32_t by0, uint32_t by1)
@@ -372,7 +301,6 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
         if (rad <= 0) continue;
         uint2 rmin, rmax;
         getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy_all);
-        if (!FULL) shrink_rect(rec.xy, rec.co, rad, rmin, rmax);
         rmin.y = max(rmin.y, by0);
         rmax.y = min(rmax.y, by1);
         if (rmax.x <= rmin.x || rmax.y <= rmin.y) continue;
@@ -412,6 +340,186 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
     }
     __syncthreads();
     for (int t = tid; t < (int)(gx * gy); t += BIN_THREADS) my_partial[t] = (uint32_t)s_grid[(t / (int)gx) * stride + (t % (int)gx)];
+}
+
+// entries[0 .. min(*n, cap)) = 0, n read on the device (16-byte stores; the tail by single words)
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* __restrict__ p, const int* __restrict__ n_ptr, int cap)
+{
+    const int n = min(*n_ptr, cap);
+    const int n4 = n >> 2;
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[4 * n4 + threadIdx.x] = 0u;
+}
+
+// ---- lean lists from row spans (the product default) ------------------------------------------------------------
+// The count and emit passes of the lean lists without a single per-tile test.  Items of the first level are (Gaussian,
+// tile row) pairs, balanced over the workgroup like the tiles of bin_ranks_kernel (a Gaussian covers 1 .. 68 rows); each
+// evaluates the two closed-form column intervals of its row's upper and lower 8-pixel band (cull.h: band_columns) and
+// gets the tile span [x0, x1) that holds them.
+//   COUNT (EMIT = false): +1 / -1 at the two ends of the span in a per-row difference grid in LDS; the prefix along x is
+//                the number of spans covering each tile -- this slice's share of the tile's segment;
+//   EMIT:        second level, the tiles of the 1024 spans of a window, balanced again: the quadrant mask of a tile is read
+//                off the two column intervals (four range tests on integers), the slot comes from the LDS cursor.
+// Measured on cfg3: 8.68 M tiles in the shrunk rects, 5.2 M in the spans; the enumerating emit pass spent 182 VALU
+// instructions per 64 rect tiles on the whole-tile test and 386 per 64 survivors on the four quadrant tests.
+// Slices (rank chunks dealt round robin), partial[][] and the cursors are those of bin_count_kernel / bin_ranks_kernel.
+constexpr int SPAN_LDS_WORDS = 3088 + 2048 + 4096 + 5 * 1024;  // RectWork + means + conics + prefix / rect / tau-free params
+
+__device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid, uint32_t* s_wsum, uint32_t& total)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = wave_inclusive_scan(v, lane);
+    __syncthreads();  // s_wsum may still be read by the previous caller
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t c = s_wsum[w];
+        woff += w < wave ? c : 0u;
+        tot += c;
+    }
+    total = tot;
+    return incl + woff;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const BlendRec* __restrict__ rank_rec,
+                                                                uint32_t* __restrict__ partial,
+                                                                const uint2* __restrict__ ranges,
+                                                                uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy_all,
+                                                                uint32_t by0, uint32_t by1, int ablate)
+{
+    // COUNT: s_dyn = difference grid [band rows][stride] (ints), then the hand-off arrays
+    // EMIT : s_dyn = cursors [band tiles], then the hand-off arrays
+    extern __shared__ uint32_t s_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t gy = by1 - by0;
+    const int stride = count_grid_stride(gx);
+    const int ntiles = (int)(gx * gy);
+    const int tile0 = (int)(gx * by0);
+    const int ntiles_all = (int)(gx * gy_all);
+    const int head = EMIT ? ((ntiles + 3) & ~3) : (((int)gy * stride + 3) & ~3);
+    uint32_t* s_cnt = s_dyn;
+    int* s_grid = reinterpret_cast<int*>(s_dyn);
+    uint32_t* s_rw = s_dyn + head;
+    RectWork rw{s_rw, s_rw + 1024, s_rw + 2048, s_rw + 3072};
+    float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);
+    float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);
+    uint32_t* s_gpre = s_rw + 3088 + 6144;   // inclusive prefix of the Gaussians' row counts
+    uint32_t* s_grect = s_gpre + 1024;       // clip columns x0 | x1 << 10, first row << 21
+    uint32_t* s_grad = s_grect + 1024;       // radius (the margin of tau needs it)
+    uint32_t* s_q0 = s_grad + 1024;          // EMIT, per span: upper band's columns lo | hi << 11, Gaussian slot << 22
+    uint32_t* s_q1 = s_q0 + 1024;            //                 lower band's columns lo | hi << 11
+    uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles_all + tile0;
+    if (EMIT) {
+        for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
+    } else {
+        for (int c = tid; c < (int)gy * stride; c += BIN_THREADS) s_grid[c] = 0;
+    }
+    __syncthreads();
+    const int nwg = (int)gridDim.x;
+    const int rounds = ((P + 63) / 64 + 16 * nwg - 1) / (16 * nwg);
+    for (int it = 0; it < rounds; it++) {
+        const int r = ((it * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
+        uint32_t h = 0;
+        if (r < P) {
+            const BlendRec rec = rank_rec[r];
+            const int rad = (int)rec.pm;
+            if (rad > 0) {
+                uint2 rmin, rmax;
+                getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy_all);
+                shrink_rect(rec.xy, rec.co, rad, rmin, rmax);
+                rmin.y = max(rmin.y, by0);
+                rmax.y = min(rmax.y, by1);
+                if (rmax.x > rmin.x && rmax.y > rmin.y) {
+                    h = rmax.y - rmin.y;
+                    s_xy[tid] = rec.xy;
+                    s_co[tid] = rec.co;
+                    s_grect[tid] = rmin.x | (rmax.x << 10) | (rmin.y << 21);
+                    s_grad[tid] = (uint32_t)rad;
+                }
+            }
+        }
+        uint32_t rows_total;
+        s_gpre[tid] = workgroup_inclusive_scan(h, tid, rw.wsum, rows_total);
+        __syncthreads();
+        if MI_ABLATE(1 << 20) rows_total = 0;
+        for (uint32_t w0 = 0; w0 < rows_total; w0 += 1024) {  // windows of 1024 (Gaussian, tile row) items
+            const uint32_t k = w0 + (uint32_t)tid;
+            uint2 smin = make_uint2(0, 0), smax = make_uint2(0, 0);
+            uint32_t width = 0;
+            if (k < rows_total) {
+                int g = 0;  // first Gaussian slot with prefix > k
+#pragma unroll
+                for (int step = 512; step >= 1; step >>= 1)
+                    if (s_gpre[g + step - 1] <= k) g += step;
+                const uint32_t prev = g == 0 ? 0u : s_gpre[g - 1];
+                const uint32_t packed = s_grect[g];
+                const uint32_t cx0 = packed & 1023u, cx1 = (packed >> 10) & 2047u, ty = (packed >> 21) + (k - prev);
+                const float2 xy = s_xy[g];
+                const SpanPre pre = span_prepare(s_co[g], (int)s_grad[g]);
+                int lo0, hi0, lo1, hi1;
+                band_columns(pre, xy, (float)(ty * TILE_Y), (int)(2u * cx0), (int)(2u * cx1), lo0, hi0);
+                band_columns(pre, xy, (float)(ty * TILE_Y + 8u), (int)(2u * cx0), (int)(2u * cx1), lo1, hi1);
+                if (hi0 > lo0 || hi1 > lo1) {
+                    const int lo = hi0 > lo0 ? (hi1 > lo1 ? min(lo0, lo1) : lo0) : lo1;
+                    const int hi = hi0 > lo0 ? (hi1 > lo1 ? max(hi0, hi1) : hi0) : hi1;
+                    smin = make_uint2((uint32_t)lo >> 1, ty);
+                    smax = make_uint2(((uint32_t)hi + 1u) >> 1, ty + 1u);
+                    width = smax.x - smin.x;
+                    if (EMIT) {
+                        s_q0[tid] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | ((uint32_t)g << 22);
+                        s_q1[tid] = (uint32_t)lo1 | ((uint32_t)hi1 << 11);
+                    } else {
+                        atomicAdd(&s_grid[(ty - by0) * stride + smin.x], 1);
+                        atomicAdd(&s_grid[(ty - by0) * stride + smax.x], -1);
+                    }
+                }
+            }
+            if (EMIT && !MI_ABLATE(1 << 16)) {
+                for_each_tile_balanced(
+                    rw, tid, smin, smax, width,
+                    [&](uint32_t owner, uint32_t tx, uint32_t ty) {
+                        if MI_ABLATE(1 << 17) return;
+                        const uint32_t q0 = s_q0[owner], q1 = s_q1[owner];
+                        const uint32_t lo0 = q0 & 2047u, n0 = ((q0 >> 11) & 2047u) - lo0, lo1 = q1 & 2047u, n1 = ((q1 >> 11) & 2047u) - lo1;
+                        const uint32_t c = 2u * tx;
+                        const uint32_t qmask = (uint32_t)(c - lo0 < n0) | ((uint32_t)(c + 1u - lo0 < n0) << 1) |
+                                               ((uint32_t)(c - lo1 < n1) << 2) | ((uint32_t)(c + 1u - lo1 < n1) << 3);
+                        if (qmask != 0u) {
+                            const uint32_t slot_g = q0 >> 22;
+                            const uint32_t rank = (uint32_t)(((it * 16 + (int)(slot_g >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(slot_g & 63u));
+                            if MI_ABLATE(1 << 18) return;
+                            const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
+                            if MI_ABLATE(1 << 19) return;
+                            entries[slot] = rank | (qmask << RANK_BITS);
+                        }
+                    });
+            }
+        }
+        __syncthreads();  // the Gaussian arrays are rewritten by the next round
+    }
+    if (!EMIT) {
+        __syncthreads();
+        // prefix along x: one wave per row, 64 cells at a time with a carry -> the per-tile counts of this slice
+        for (int y = wave; y < (int)gy; y += BIN_THREADS / 64) {
+            int carry = 0;
+            for (int x0 = 0; x0 < (int)gx; x0 += 64) {
+                const int x = x0 + lane;
+                int v = x < (int)gx ? s_grid[y * stride + x] : 0;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(v, o, 64);
+                    if (lane >= o) v += t;
+                }
+                v += carry;
+                if (x < (int)gx) my_partial[y * (int)gx + x] = (uint32_t)v;
+                carry = __shfl(v, 63, 64);
+            }
+        }
+    }
 }
 
 // Per tile: exclusive prefix of partial[slice][tile] over the slices (in place) and tile_total[tile].

@@ -338,11 +338,13 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (prefiltered) HIP_TRY(hipMemsetAsync(cull_counter, 0, sizeof(int), stream));
     const int ntiles = (int)(vp.grid_x * vp.grid_y);
     if (P >= (1 << RANK_BITS)) return fail(MI_RAST_ERR_INVALID, "more than 2^28 Gaussians");
-    if (vp.grid_x > 2047u || vp.grid_y > 2047u) return fail(MI_RAST_ERR_INVALID, "image too large: more than 2047 tiles along one axis");
+    if (vp.grid_x > 1023u || vp.grid_y > 2047u)
+        return fail(MI_RAST_ERR_INVALID, "image too large: more than 1023 tiles across or 2047 tiles down");
     if (ntiles > BIN_MAX_TILES_TOTAL)
         return fail(MI_RAST_ERR_INVALID, "image too large: more than 40896 tiles (e.g. 4096 x 2544 px at 16-px tiles)");
     // images with more tiles than one launch of the count / emit passes has LDS counters for are walked in bands of tile rows
-    const uint32_t band_rows = std::min<uint32_t>(vp.grid_y, std::max<uint32_t>(1u, (uint32_t)BIN_MAX_TILES / vp.grid_x));
+    // (grid_x + 2: the count passes keep band_rows (+ 1) rows of an odd stride >= grid_x + 1 in the same LDS budget)
+    const uint32_t band_rows = std::min<uint32_t>(vp.grid_y, std::max<uint32_t>(1u, (uint32_t)BIN_MAX_TILES / (vp.grid_x + 2u) - 1u));
     const uint32_t nbands = (vp.grid_y + band_rows - 1) / band_rows;
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
@@ -366,11 +368,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             const int max_lds = (int)((BIN_MAX_TILES + 11 * 1024 + 16) * sizeof(uint32_t));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -412,7 +412,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     // `debug` flag or MI_RAST_FULL_LISTS -- ; otherwise only the overlaps that pass the cull are listed.
     const bool nocull = (flags & MI_RAST_NO_CULL) != 0;
     const bool full = debug != 0 || nocull || (flags & MI_RAST_FULL_LISTS) != 0;
-    const int nwg = bin_workgroups(P);
+    int nwg = bin_workgroups(P);
+#ifdef MI_RAST_PROFILING
+    if (ablate_env("MI_RAST_NWG") > 0) nwg = std::min(nwg, ablate_env("MI_RAST_NWG"));
+#endif
     const size_t band_tiles = (size_t)band_rows * vp.grid_x;
     const size_t bin_lds = ((size_t)((band_tiles + 3) & ~(size_t)3) + 3 * 1024 + 16) * sizeof(uint32_t);
     {
@@ -421,23 +424,14 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         const size_t cnt_lds = (size_t)(band_rows + 1) * count_grid_stride(vp.grid_x) * sizeof(int);
         for (uint32_t b = 0; b < nbands; b++) {
             const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
-#ifdef MI_RAST_PROFILING
-            if (g_ablate_fwd & 4096) {  // the enumerating count pass (MI_RAST_ABLATE_FWD=4096: comparisons)
-                if (full)
-                    hipLaunchKernelGGL((bin_ranks_kernel<false, true>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
-                                       img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y, by0, by1);
-                else
-                    hipLaunchKernelGGL((bin_ranks_kernel<false, false>), dim3(nwg), dim3(BIN_THREADS), bin_lds, stream, P, geom.rank_rec,
-                                       img.tile_count, img.ranges, (uint32_t*)nullptr, vp.grid_x, vp.grid_y, by0, by1);
-                continue;
-            }
-#endif
             if (full)
-                hipLaunchKernelGGL(bin_count_kernel<true>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
+                hipLaunchKernelGGL(bin_count_kernel, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
                                    img.tile_count, vp.grid_x, vp.grid_y, by0, by1);
             else
-                hipLaunchKernelGGL(bin_count_kernel<false>, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
-                                   img.tile_count, vp.grid_x, vp.grid_y, by0, by1);
+                hipLaunchKernelGGL(bin_spans_kernel<false>, dim3(nwg), dim3(BIN_THREADS),
+                                   ((((size_t)(by1 - by0) * count_grid_stride(vp.grid_x) + 3) & ~(size_t)3) + SPAN_LDS_WORDS) * sizeof(uint32_t),
+                                   stream, P, geom.rank_rec, img.tile_count, (const uint2*)nullptr, (uint32_t*)nullptr, vp.grid_x,
+                                   vp.grid_y, by0, by1, g_ablate_fwd);
         }
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
@@ -465,19 +459,24 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            if (!full) HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint32_t), stream));
+            // lean: the segments are upper bounds of the lists, unused slots stay 0 (the per-tile sort drops them)
+            // (only the first `total of the range scan` words are segments; that number is still on its way to the host)
+            if (!full)
+                hipLaunchKernelGGL(zero_words_kernel, dim3(2048), dim3(256), 0, stream, bin.entries,
+                                   (const int*)(img.num_rendered + R_SLOTS * R_SLOT_STRIDE), R);
             const size_t emit_lds = bin_lds + 8 * 1024 * sizeof(uint32_t);
             for (uint32_t b = 0; b < nbands; b++) {
                 const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
                 if (nocull)
-                    hipLaunchKernelGGL((bin_ranks_kernel<true, true, true>), dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
+                    hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
                 else if (full)
-                    hipLaunchKernelGGL((bin_ranks_kernel<true, true>), dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
+                    hipLaunchKernelGGL(bin_ranks_kernel<false>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
                 else
-                    hipLaunchKernelGGL((bin_ranks_kernel<true, false>), dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
-                                       img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
+                    hipLaunchKernelGGL(bin_spans_kernel<true>, dim3(nwg), dim3(BIN_THREADS),
+                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + SPAN_LDS_WORDS) * sizeof(uint32_t), stream, P,
+                                       geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1, g_ablate_fwd);
             }
         }
         STAGE_CHECK("emit ranks");
