@@ -555,7 +555,11 @@ __global__ void __launch_bounds__(1024) scan_partials_kernel(int ntiles, int nwg
 // LSD radix, 8-bit digits, `passes` = ceil(rank_bits / 8).  Each wave owns a contiguous quarter of the tile's
 // list; per pass: per-wave digit histograms -> workgroup scan over (digit, wave) -> each wave scatters its quarter
 // 64 keys at a time with a stable ballot-match rank.  Three workgroup barriers per pass.
-template <int NW, typename SrcPtr, typename DstPtr>
+// MAXB > 0 (lists held in LDS: a wave's share is at most MAXB batches of 64 keys): the keys and their match results
+// (rank among the wave's equal digits, size of that group) stay in registers between the histogram and the scatter
+// phase -- the eight-ballot match is evaluated once per key and pass instead of twice.  MAXB = 0: any length (the
+// HBM fallback), everything re-read and re-matched in the scatter phase.
+template <int NW, int MAXB, typename SrcPtr, typename DstPtr>
 __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int shift, uint32_t (*s_hist)[256], int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -577,15 +581,31 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
         cnt = (uint32_t)__builtin_popcountll(m);
     };
 
+    constexpr int NB = MAXB > 0 ? MAXB : 1;
+    uint32_t c_key[NB], c_rk[NB], c_cnt[NB];
     // (a) per-wave histogram of this digit
-    for (int i0 = begin; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const bool active = i < end;
-        const uint32_t key = active ? (uint32_t)src[i] : 0u;
-        const uint32_t digit = ((key & RANK_MASK) >> shift) & 0xFFu;
-        uint32_t rk, cnt;
-        match(digit, active, rk, cnt);
-        if (active && rk == 0) s_hist[wave][digit] += cnt;  // one lane per distinct digit, wave-private row
+    if (MAXB > 0) {
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const int i0 = begin + 64 * j;
+            if (i0 >= end) break;  // wave-uniform
+            const int i = i0 + lane;
+            const bool active = i < end;
+            c_key[j] = active ? (uint32_t)src[i] : 0u;
+            const uint32_t digit = ((c_key[j] & RANK_MASK) >> shift) & 0xFFu;
+            match(digit, active, c_rk[j], c_cnt[j]);
+            if (active && c_rk[j] == 0) s_hist[wave][digit] += c_cnt[j];  // one lane per distinct digit, wave-private row
+        }
+    } else {
+        for (int i0 = begin; i0 < end; i0 += 64) {
+            const int i = i0 + lane;
+            const bool active = i < end;
+            const uint32_t key = active ? (uint32_t)src[i] : 0u;
+            const uint32_t digit = ((key & RANK_MASK) >> shift) & 0xFFu;
+            uint32_t rk, cnt;
+            match(digit, active, rk, cnt);
+            if (active && rk == 0) s_hist[wave][digit] += cnt;
+        }
     }
     __syncthreads();
     // (b) exclusive scan over (digit major, wave minor): thread d < 256 owns digit d
@@ -613,19 +633,32 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
         }
     }
     __syncthreads();
-    // (c) stable scatter of this wave's quarter; s_hist[wave][digit] is now this wave's running cursor
-    for (int i0 = begin; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const bool active = i < end;
-        const uint32_t key = active ? (uint32_t)src[i] : 0u;
+    // (c) stable scatter of this wave's share; s_hist[wave][digit] is now this wave's running cursor
+    auto scatter = [&](uint32_t key, bool active, uint32_t rk, uint32_t cnt) {
         const uint32_t digit = ((key & RANK_MASK) >> shift) & 0xFFu;
-        uint32_t rk, cnt;
-        match(digit, active, rk, cnt);
         uint32_t off = 0;
         if (active) off = s_hist[wave][digit] + rk;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (active && rk == cnt - 1) s_hist[wave][digit] = off + 1;  // last lane of the group advances the cursor
         if (active) dst[off] = key;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    if (MAXB > 0) {
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const int i0 = begin + 64 * j;
+            if (i0 >= end) break;
+            scatter(c_key[j], i0 + lane < end, c_rk[j], c_cnt[j]);
+        }
+    } else {
+        for (int i0 = begin; i0 < end; i0 += 64) {
+            const int i = i0 + lane;
+            const bool active = i < end;
+            const uint32_t key = active ? (uint32_t)src[i] : 0u;
+            uint32_t rk, cnt;
+            match(((key & RANK_MASK) >> shift) & 0xFFu, active, rk, cnt);
+            scatter(key, active, rk, cnt);
+        }
     }
     __syncthreads();
 }
@@ -778,7 +811,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__
         uint32_t* a = s_a;
         uint32_t* b = s_b;
         for (int p = 0; p < passes; p++) {
-            radix_pass<NW>(a, b, m, 8 * p, s_hist, tid);
+            radix_pass<NW, (CAP + NW * 64 - 1) / (NW * 64)>(a, b, m, 8 * p, s_hist, tid);
             uint32_t* t = a;
             a = b;
             b = t;
@@ -795,7 +828,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__
             b = seg;
         }
         for (int p = 0; p < passes; p++) {
-            radix_pass<NW>(a, b, m, 8 * p, s_hist, tid);
+            radix_pass<NW, 0>(a, b, m, 8 * p, s_hist, tid);
             uint32_t* t = a;
             a = b;
             b = t;
