@@ -342,23 +342,14 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
     for (int t = tid; t < (int)(gx * gy); t += BIN_THREADS) my_partial[t] = (uint32_t)s_grid[(t / (int)gx) * stride + (t % (int)gx)];
 }
 
-// entries[0 .. min(*n, cap)) = 0, n read on the device (16-byte stores; the tail by single words)
-__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* __restrict__ p, const int* __restrict__ n_ptr, int cap)
-{
-    const int n = min(*n_ptr, cap);
-    const int n4 = n >> 2;
-    uint4* p4 = reinterpret_cast<uint4*>(p);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) p4[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[4 * n4 + threadIdx.x] = 0u;
-}
-
 // ---- lean lists from row spans (the product default) ------------------------------------------------------------
 // The count and emit passes of the lean lists without a single per-tile test.  Items of the first level are (Gaussian,
 // tile row) pairs, balanced over the workgroup like the tiles of bin_ranks_kernel (a Gaussian covers 1 .. 68 rows); each
 // evaluates the two closed-form column intervals of its row's upper and lower 8-pixel band (cull.h: band_columns) and
 // gets the tile span [x0, x1) that holds them.
 //   COUNT (EMIT = false): +1 / -1 at the two ends of the span in a per-row difference grid in LDS; the prefix along x is
-//                the number of spans covering each tile -- this slice's share of the tile's segment;
+//                the number of spans covering each tile -- this slice's share of the tile's segment, EXACTLY: a tile is
+//                counted iff the emit pass stores an entry for it, so the segments have no unused slots;
 //   EMIT:        second level, the tiles of the 1024 spans of a window, balanced again: the quadrant mask of a tile is read
 //                off the two column intervals (four range tests on integers), the slot comes from the LDS cursor.
 // Measured on cfg3: 8.68 M tiles in the shrunk rects, 5.2 M in the spans; the enumerating emit pass spent 182 VALU
@@ -473,8 +464,19 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
                         s_q0[tid] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | ((uint32_t)g << 22);
                         s_q1[tid] = (uint32_t)lo1 | ((uint32_t)hi1 << 11);
                     } else {
-                        atomicAdd(&s_grid[(ty - by0) * stride + smin.x], 1);
-                        atomicAdd(&s_grid[(ty - by0) * stride + smax.x], -1);
+                        // EXACT counts: a tile is counted iff one of the two intervals has a column in it, i.e. iff the emit
+                        // pass finds a non-zero mask there -- the two bands' tile ranges separately when a gap lies between them
+                        int* row = s_grid + (ty - by0) * stride;
+                        const int a0 = lo0 >> 1, b0 = (hi0 + 1) >> 1, a1 = lo1 >> 1, b1 = (hi1 + 1) >> 1;
+                        if (hi0 > lo0 && hi1 > lo1 && (b0 < a1 || b1 < a0)) {
+                            atomicAdd(&row[a0], 1);
+                            atomicAdd(&row[b0], -1);
+                            atomicAdd(&row[a1], 1);
+                            atomicAdd(&row[b1], -1);
+                        } else {
+                            atomicAdd(&row[smin.x], 1);
+                            atomicAdd(&row[smax.x], -1);
+                        }
                     }
                 }
             }
@@ -724,42 +726,6 @@ __device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, SparePtr 
     if (tid == 0) blend_count[tile] = ns;
 }
 
-// Lean lists: the non-zero entries of a zero-filled segment, compacted into dst (order irrelevant: they are sorted
-// next); returns their number.  Every wave owns a contiguous share; one barrier exchanges the counts.
-template <int NW, typename SrcPtr, typename DstPtr>
-__device__ __forceinline__ int compact_nonzero(SrcPtr src, DstPtr dst, int n, int tid, uint32_t* s_wcount)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    const int chunks = (n + 63) >> 6;
-    const int cpw = (chunks + NW - 1) / NW;
-    const int begin = min(n, wave * cpw * 64), end = min(n, (wave + 1) * cpw * 64);
-    uint32_t mine = 0;
-    for (int i0 = begin; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const uint32_t v = i < end ? (uint32_t)src[i] : 0u;
-        mine += (uint32_t)__builtin_popcountll(ballot64(v != 0u));
-    }
-    if (lane == 0) s_wcount[wave] = mine;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        const uint32_t c = s_wcount[w];
-        base += w < wave ? c : 0u;
-        total += c;
-    }
-    for (int i0 = begin; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const uint32_t v = i < end ? (uint32_t)src[i] : 0u;
-        const uint64_t bal = ballot64(v != 0u);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (v != 0u) dst[base + below] = v;
-        base += (uint32_t)__builtin_popcountll(bal);
-    }
-    __syncthreads();
-    return (int)total;
-}
-
 // Lean lists: every sorted entry is a survivor; its position in the blend list stands in for the position in the
 // reference's full list (the blend kernels only compare positions of one list with each other).
 template <int NW, typename SrcPtr>
@@ -799,15 +765,9 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__
     if (n > CAP && !GLOBAL_FALLBACK) return;
     uint32_t* seg = entries + range.x;
     if (n <= CAP) {
-        int m = n;
-        if (FULL) {
-            for (int i = tid; i < n; i += NT) s_a[i] = seg[i];
-            __syncthreads();
-        } else {
-            for (int i = tid; i < n; i += NT) s_b[i] = seg[i];
-            __syncthreads();
-            m = compact_nonzero<NW>(s_b, s_a, n, tid, s_wcount);
-        }
+        const int m = n;  // lean lists too: their counts are exact (bin_spans_kernel), every slot of the segment holds an entry
+        for (int i = tid; i < n; i += NT) s_a[i] = seg[i];
+        __syncthreads();
         uint32_t* a = s_a;
         uint32_t* b = s_b;
         for (int p = 0; p < passes; p++) {
@@ -821,12 +781,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
-        int m = n;
-        if (!FULL) {
-            m = compact_nonzero<NW>(seg, b, n, tid, s_wcount);
-            a = b;
-            b = seg;
-        }
+        const int m = n;
         for (int p = 0; p < passes; p++) {
             radix_pass<NW, 0>(a, b, m, 8 * p, s_hist, tid);
             uint32_t* t = a;

@@ -459,11 +459,6 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (R > 0) {
         {
             StageTimer t(stream, MI_STAGE_EMIT);
-            // lean: the segments are upper bounds of the lists, unused slots stay 0 (the per-tile sort drops them)
-            // (only the first `total of the range scan` words are segments; that number is still on its way to the host)
-            if (!full)
-                hipLaunchKernelGGL(zero_words_kernel, dim3(2048), dim3(256), 0, stream, bin.entries,
-                                   (const int*)(img.num_rendered + R_SLOTS * R_SLOT_STRIDE), R);
             const size_t emit_lds = bin_lds + 8 * 1024 * sizeof(uint32_t);
             for (uint32_t b = 0; b < nbands; b++) {
                 const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
@@ -504,7 +499,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     } while (0)
             LAUNCH_TILE_SORT(0, 2048, false, 256);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
-            // lean lists: the counts are those of the shrunk rects, an upper bound of the lists and a lower bound of R
+            // lean lists: the counts are the lists' exact lengths (bin_spans_kernel), their sum a lower bound of R
             if (full ? g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R : g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] > R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
