@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dist-single", action="store_true",
                     help="testing only: initialise torch.distributed (RCCL) with a single rank and run the N > 1 step")
+    ap.add_argument("--settle", type=float, default=3.0,
+                    help="minimum seconds of untimed settling blocks before the W warm-up steps (0 under a profiler: the "
+                         "trace would hold thousands of views)")
     ap.add_argument("--fast-exp", action="store_true",
                     help="run the product in its MI_RAST_FAST_EXP mode (v_exp_f32 instead of expf; noted in "
                          "config.arithmetic -- the headline number is the default mode)")
@@ -214,7 +217,8 @@ def main():
         now = time.perf_counter()
         block_ms.append(round(1e3 * (now - tb) / nb, 3))
         last = block_ms[-5:]
-        settled = (len(block_ms) >= 5 and max(last) <= 1.05 * min(block_ms) and now - t_settle >= 3.0) or now - t_settle >= 20.0
+        settled = ((len(block_ms) >= 5 and max(last) <= 1.05 * min(block_ms) and now - t_settle >= args.settle) or now - t_settle >= 20.0
+                   or args.settle <= 0)
         if dist is not None:   # every rank must run the same number of steps (each step holds a collective)
             flag = torch.tensor([0 if settled else 1], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)

@@ -379,7 +379,23 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(
     float* __restrict__ dL_dcov, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
+    if (idx >= P) return;
+    if (!(radii[idx] > 0)) {
+        // Not rendered: every gradient of this Gaussian is zero.  Written here, so that the caller need not zero-fill these
+        // outputs (include/mi_rast.h; the reference's glue zero-fills all of them, rasterize_points.cu:151-159: 96 B per
+        // Gaussian of HBM writes that four fifths of the rows overwrite).  dL_dcolor and dL_dsh are accumulated into and stay
+        // the caller's to clear.
+        dL_dmean2D[3 * idx + 0] = dL_dmean2D[3 * idx + 1] = dL_dmean2D[3 * idx + 2] = 0.f;
+        reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dL_dopacity[idx] = 0.f;
+        if (dL_dmask) dL_dmask[idx] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) dL_dcov[(size_t)idx * 6 + i] = 0.f;
+        dL_dmeans[3 * idx + 0] = dL_dmeans[3 * idx + 1] = dL_dmeans[3 * idx + 2] = 0.f;
+        dL_dscale[3 * idx + 0] = dL_dscale[3 * idx + 1] = dL_dscale[3 * idx + 2] = 0.f;
+        reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
 
     // unpack the per-Gaussian record written by the blend backward: {mean2D.x, mean2D.y, conic.x, conic.y,
     // conic.w, opacity, mask, -} -> the reference's dL_dmean2D (P,3), dL_dconic (P,2,2), dL_dopacity, dL_dmask
@@ -387,6 +403,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(
     const float4 g1 = reinterpret_cast<const float4*>(gpack)[2 * idx + 1];
     dL_dmean2D[3 * idx + 0] = g0.x;
     dL_dmean2D[3 * idx + 1] = g0.y;
+    dL_dmean2D[3 * idx + 2] = 0.f;  // never written by the reference either (backward.cu:541-542): stays the glue's zero
     reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(g0.z, g0.w, 0.f, g1.x);
     dL_dopacity[idx] = g1.y;
     if (dL_dmask) dL_dmask[idx] = g1.z;
@@ -484,6 +501,9 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(
         dL_dscale[3 * idx + 1] = ds.y;
         dL_dscale[3 * idx + 2] = ds.z;
         reinterpret_cast<float4*>(dL_drot)[idx] = dq;
+    } else {  // cov3D_precomp given: no scale / rotation gradient (backward.cu:390-394)
+        dL_dscale[3 * idx + 0] = dL_dscale[3 * idx + 1] = dL_dscale[3 * idx + 2] = 0.f;
+        reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 

@@ -207,25 +207,28 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
     M = sh.size(1) if sh.numel() != 0 else 0
     dev = means3D.device
     o = dict(device=dev, dtype=torch.float32)
-    # The reference allocates ten zero tensors (rasterize_points.cu:151-159).  Same tensors here, carved from TWO
-    # zero-filled blocks: two fill launches instead of ten (each small fill costs a launch, ~5 us, on this part).
-    # dL_dcolors -- the one gradient SAGA's feature training keeps (`_point_features.grad`) -- has its own storage, so
-    # holding it does not pin the geometry gradients and the internal scratch (dL_dconic, unused dL_dcov3D / dL_dsh),
-    # which share the second block.
+    # The reference allocates ten zero tensors (rasterize_points.cu:151-159).  Same tensors here: dL_dcolors and dL_dsh,
+    # which the kernels accumulate into, zero-filled; the others carved from ONE uninitialised block that
+    # mi_rast_backward writes in full (zeros for Gaussians that were not rendered, include/mi_rast.h) -- 96 B per Gaussian
+    # of fill traffic and nine fill launches less.  dL_dcolors -- the one gradient SAGA's feature training keeps
+    # (`_point_features.grad`) -- has its own storage, so holding it does not pin the geometry gradients.
+    # `debug` poisons the block with NaN first: a row the library failed to write would surface in the gradients.
     shapes = [("dL_dmeans3D", (P, 3)), ("dL_dmeans2D", (P, 3)), ("dL_dcolors", (P, channels)), ("dL_dconic", (P, 2, 2)),
               ("dL_dopacity", (P, 1)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)),
               ("dL_drotations", (P, 4))]
     if with_mask_depth:
         shapes.append(("dL_dmask", (P, 1)))   # DEPTH/rasterize_points.cu:167: torch::zeros({P, 1})
-    shapes = [x for x in shapes if x[0] != "dL_dcolors"]
+    shapes = [x for x in shapes if x[0] not in ("dL_dcolors", "dL_dsh")]
     sizes = []
     for _n, shp in shapes:
         n = 1
         for d in shp:
             n *= d
         sizes.append((n + 3) // 4 * 4)  # keep every tensor 16-byte aligned
-    flat = torch.zeros(sum(sizes), **o)
-    g = {"dL_dcolors": torch.zeros((P, channels), **o)}
+    flat = torch.empty(sum(sizes), **o)
+    if debug:
+        flat.fill_(float("nan"))
+    g = {"dL_dcolors": torch.zeros((P, channels), **o), "dL_dsh": torch.zeros((P, M, 3), **o)}
     off = 0
     for (name, shp), n in zip(shapes, sizes):
         cnt = 1

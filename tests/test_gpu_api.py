@@ -233,3 +233,26 @@ def test_bench_single_rank_rccl_step():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["counters"]["P"] == 200000
     assert set(line["roofline"]["stages"]) >= {"preprocess", "blend_fwd", "blend_bwd", "geom_bwd"}
+
+
+@pytest.mark.parametrize("use_cov", [False, True])
+def test_backward_writes_every_gradient_row(use_cov):
+    """include/mi_rast.h: only dL_dcolor / dL_dsh must be cleared by the caller; every other gradient output is written in
+    full by mi_rast_backward -- zeros for Gaussians that were not rendered (behind the camera, outside the frustum, zero-area
+    rect), zeros for scales / rotations when cov3D_precomp is given.  With `debug` the glue hands the library a NaN-poisoned
+    block, so a row it failed to write shows up; values are compared with the oracle's (the reference's zero-filled tensors)."""
+    inp = hp.make_inputs(4000, 160, 112, 32, seed=5, camera="orbit", use_cov=use_cov)
+    g = hp.GpuRun(inp).forward(debug=True)
+    radii = g.radii.cpu().numpy()
+    assert (radii == 0).sum() > 100 and (radii > 0).sum() > 1000   # the scene has both kinds
+    dL = scenes.make_grad_image(32, 112, 160, seed=3)
+    grads = g.backward(dL, debug=True)
+    of = so.forward(inp)
+    ob = so.backward(inp, of, dL)
+    for k, v in grads.items():
+        assert np.isfinite(v).all(), k
+        if k != "dL_dcolors":
+            assert not v[radii == 0].any(), k
+    hp.compare_gradients(grads, ob)
+    if use_cov:
+        assert not grads["dL_dscales"].any() and not grads["dL_drotations"].any()
