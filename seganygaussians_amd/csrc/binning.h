@@ -41,6 +41,15 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
     return v;
 }
 
+// Row of partial[][] (= position of the slice inside every tile's segment) of workgroup b.  Workgroup b runs on XCD b % 8
+// (tools/xcc_probe.hip) and each XCD has its own L2: with the slices of one XCD next to each other, the 4-byte entries that
+// share a 128-byte line of a tile's segment are mostly written through ONE L2 instead of eight (the emit pass wrote 160 MB
+// to HBM for 12 MB of entries).  Any bijection is correct -- count, scan and emit only have to agree on it.
+__device__ __forceinline__ uint32_t slice_row(uint32_t b, uint32_t nwg)
+{
+    return (nwg & 7u) ? b : (b & 7u) * (nwg >> 3) + (b >> 3);
+}
+
 struct RectWork {
     uint32_t* prefix;  // LDS [1024] inclusive prefix of counts
     uint32_t* rx;      // LDS [1024] rect_min.x | width << 16
@@ -239,7 +248,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
     float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);          // the owners' means ...
     float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);   // ... conics + opacities ...
     uint32_t* s_rad = s_rw + 3088 + 6144;                           // ... and radii
-    const uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles_all + tile0;
+    const uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * ntiles_all + tile0;
     for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
     __syncthreads();
     // 64-rank chunks are dealt round robin over all the waves of all the workgroups: chunk c belongs to workgroup
@@ -330,7 +339,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
     }
     __syncthreads();
     // prefix along y: one thread per column; the running sums are the per-tile counts of this slice
-    uint32_t* my_partial = partial + (size_t)blockIdx.x * (gx * gy_all) + (size_t)gx * by0;
+    uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * (gx * gy_all) + (size_t)gx * by0;
     for (int x = tid; x < (int)gx; x += BIN_THREADS) {
         int run = 0;
         for (int y = 0; y < (int)gy; y++) {
@@ -403,7 +412,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
     uint32_t* s_grad = s_grect + 1024;       // radius (the margin of tau needs it)
     uint32_t* s_q0 = s_grad + 1024;          // EMIT, per span: upper band's columns lo | hi << 11, Gaussian slot << 22
     uint32_t* s_q1 = s_q0 + 1024;            //                 lower band's columns lo | hi << 11
-    uint32_t* my_partial = partial + (size_t)blockIdx.x * ntiles_all + tile0;
+    uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * ntiles_all + tile0;
     if (EMIT) {
         for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
     } else {

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(1024) depth_bucket_kernel(int P, const uint32_
     extern __shared__ uint32_t s_dyn[];  // [DS_NBK] counters / cursors
     const int tid = threadIdx.x;
     const DepthMap dm = depth_map(r_slots);
-    uint32_t* my_partial = partial + (size_t)blockIdx.x * DS_NBK;
+    uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * DS_NBK;  // slices of one XCD adjacent (binning.h)
     for (int b = tid; b < DS_NBK; b += 1024) s_dyn[b] = EMIT ? ranges[b].x + my_partial[b] : 0u;
     __syncthreads();
     for (int i = blockIdx.x * 1024 + tid; i < P; i += gridDim.x * 1024) {

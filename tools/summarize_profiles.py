@@ -27,9 +27,9 @@ def short(n):
 
 
 STAGE_OF = {"blend_bwd_wave_kernel": "blend_bwd", "blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_mfma_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "blend_fwd_x3_kernel": "blend_fwd",
-            "preprocess_fwd_kernel": "preprocess", "bin_spans_kernel<true>": "emit", "bin_spans_kernel<false>": "tile_scan", "zero_words_kernel": "emit", "bin_ranks_kernel<false>": "emit", "bin_ranks_kernel<true>": "emit", "bin_ranks_kernel<true, false>": "emit", "bin_ranks_kernel<true, false, false>": "emit",
+            "preprocess_fwd_kernel": "preprocess", "bin_spans_kernel<true>": "emit", "bin_spans_kernel<false>": "tile_scan", "bin_ranks_kernel<true, false>": "emit", "bin_ranks_kernel<true, false, false>": "emit",
             "tile_sort_kernel": "tile_sort",
-            "bin_ranks_kernel<false, false>": "tile_scan", "bin_count_kernel<false>": "tile_scan", "bin_count_kernel": "tile_scan", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
+            "bin_ranks_kernel<false, false>": "tile_scan", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
             "depth_bucket_kernel<false>": "depth_sort", "depth_bucket_kernel<true>": "depth_sort",
             "depth_bucket_sort_kernel": "depth_sort", "depth_bucket_sort_wave_kernel": "depth_sort", "geometry_bwd_kernel": "geom_bwd"}
 
@@ -58,7 +58,7 @@ def pmc(name):
         return out
     for r in csv.DictReader(open(path)):
         k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("mirast::", "")
-        if not (k.startswith("bin_ranks_kernel") or k.startswith("depth_bucket_kernel")):
+        if not (k.startswith("bin_spans_kernel") or k.startswith("depth_bucket_kernel")):
             k = re.sub(r"<.*", "", k)
         out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
