@@ -83,7 +83,7 @@ def _close(got, want, rtol=1e-4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg3", help="cfg3 (default, headline) | cfg5 | cfg2 (forward only) | cfg1")
     ap.add_argument("--points", type=int, default=None, help="override Gaussian count (debug only; invalidates the metric)")
@@ -156,6 +156,7 @@ def main():
     dL = t(scenes.make_grad_image(C, H, W, seed=1))
 
     state = {}
+    host_trace = [] if os.environ.get("MI_BENCH_HOST_TRACE") else None
 
     def step():
         if args.fast_exp:
@@ -180,10 +181,14 @@ def main():
         ev, _keep = state.pop("pending", (None, None))
         if ev is not None:
             R.set_features_ready_event(ev)
+        t_a = time.perf_counter()
         means2D = torch.zeros_like(means3D, requires_grad=True)
         color, radii = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=feats, opacities=opac,
                                   scales=scales, rotations=rots, cov3D_precomp=None)
+        t_b = time.perf_counter()
         torch.autograd.backward(color, grad_tensors=dL)
+        if host_trace is not None:   # MI_BENCH_HOST_TRACE: host time of the two calls of every step (no extra syncs)
+            host_trace.append((t_a, t_b, time.perf_counter()))
         if dist is not None:
             # sum the per-Gaussian feature gradients of the N views over RCCL/xGMI: one flat 128-MB bucket, asynchronous
             state["pending"] = allreduce_grads_async([feats.grad])
@@ -242,6 +247,17 @@ def main():
     if rank == 0:
         print(f"[bench] {len(block_ms)} settling blocks of {nb} steps, ms/step: first {block_ms[:8]} min {min(block_ms)} "
               f"last {block_ms[-5:]}; timed region {ms_per_step:.3f} ms/step", file=sys.stderr)
+    if host_trace is not None and rank == 0:
+        f = sorted(1e3 * (b - a) for a, b, c in host_trace)
+        g = sorted(1e3 * (c - b) for a, b, c in host_trace)
+        print(f"[bench] host ms per call over {len(f)} steps: forward median {f[len(f) // 2]:.3f} max {f[-1]:.1f}; "
+              f"backward median {g[len(g) // 2]:.3f} max {g[-1]:.1f}", file=sys.stderr)
+        t00 = host_trace[0][0]
+        for i, (a, b, c) in enumerate(host_trace):
+            if c - a > 0.01:
+                gap = 1e3 * (a - host_trace[i - 1][2]) if i else 0.0
+                print(f"[bench]   step {i} at {a - t00:.3f} s: forward call {1e3 * (b - a):.1f} ms, backward call {1e3 * (c - b):.1f} ms, "
+                      f"gap before {gap:.1f} ms", file=sys.stderr)
     if os.environ.get("MI_BENCH_STEP_TRACE"):
         # diagnosis aid, after the timed region: wall time of single synchronised steps
         per = []

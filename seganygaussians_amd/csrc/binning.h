@@ -43,8 +43,8 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
 
 // Row of partial[][] (= position of the slice inside every tile's segment) of workgroup b.  Workgroup b runs on XCD b % 8
 // (tools/xcc_probe.hip) and each XCD has its own L2: with the slices of one XCD next to each other, the 4-byte entries that
-// share a 128-byte line of a tile's segment are mostly written through ONE L2 instead of eight (the emit pass wrote 160 MB
-// to HBM for 12 MB of entries).  Any bijection is correct -- count, scan and emit only have to agree on it.
+// share a 128-byte line of a tile's segment are mostly stored from ONE XCD instead of eight (measured: emit 0.086 -> 0.074 ms;
+// the HBM write bytes of the pass did not change).  Any bijection is correct -- count, scan and emit only have to agree on it.
 __device__ __forceinline__ uint32_t slice_row(uint32_t b, uint32_t nwg)
 {
     return (nwg & 7u) ? b : (b & 7u) * (nwg >> 3) + (b >> 3);

@@ -1,0 +1,10 @@
+# Bench lines of the current build for profiles/<tag>_bench_lines.md (run on the GPU box through gpurun).
+TAG=${1:-r02e}
+OUT=gpurun_out/lines_$TAG
+mkdir -p $OUT
+python bench.py --ref-on-gpu > $OUT/cfg3.log 2>&1
+python bench.py --config cfg2 > $OUT/cfg2.log 2>&1
+python bench.py --config cfg5 --ref-on-gpu > $OUT/cfg5.log 2>&1
+python bench.py --config cfg1 > $OUT/cfg1.log 2>&1
+python bench.py --dist-single --steps 10 --warmup 3 > $OUT/dist.log 2>&1
+python bench.py --fast-exp --no-cpu-baseline > $OUT/fastexp.log 2>&1
