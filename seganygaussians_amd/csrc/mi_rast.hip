@@ -389,7 +389,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         StageTimer t(stream, MI_STAGE_DEPTH_SORT);
         // depth ordering -> sorted_idx[rank] and the per-rank geometry records (depth_sort.h): 6 launches
         const DepthScratch ds = depth_scratch(geom.sort_temp, P);
-        const int nwg_d = depth_workgroups(P);
+        int nwg_d = depth_workgroups(P);
+#ifdef MI_RAST_PROFILING
+        if (ablate_env("MI_RAST_NWG_D") > 0) nwg_d = std::min(nwg_d, ablate_env("MI_RAST_NWG_D"));
+#endif
         int idx_bits = 1;
         while ((1ll << idx_bits) < (long long)P) idx_bits++;
         const int idx_passes = (idx_bits + 7) / 8;
