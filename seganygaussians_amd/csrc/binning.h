@@ -111,7 +111,7 @@ constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
                                                            uint32_t big_threshold, int big_limit,
-                                                           uint32_t* __restrict__ big_list)
+                                                           uint32_t* __restrict__ big_list, int* __restrict__ host_out = nullptr)
 {
     // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
     // one workgroup scan joins the pieces, and the ranges leave coalesced again.  Items below big_limit with more
@@ -162,6 +162,10 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uin
     if (tid == 0) {
         num_rendered[0] = (int)total;       // R (the host already has it from the preprocess pass; kept for checks)
         num_rendered[1] = (int)s_maxcount;  // longest list
+        if (host_out != nullptr) {          // the same two words straight into the host's pinned buffer (no copy command)
+            host_out[0] = (int)total;
+            host_out[1] = (int)s_maxcount;
+        }
         if (big_list != nullptr) big_list[0] = s_nbig;
     }
 }

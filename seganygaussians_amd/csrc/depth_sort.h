@@ -70,10 +70,13 @@ __global__ void __launch_bounds__(1024) depth_bucket_kernel(int P, const uint32_
                                                             const uint2* __restrict__ ranges, uint2* __restrict__ pairs,
                                                             uint32_t* __restrict__ sorted_idx,
                                                             BlendRec* __restrict__ rank_rec,
-                                                            const int* __restrict__ r_slots)
+                                                            const int* __restrict__ r_slots, int* __restrict__ host_r = nullptr)
 {
     extern __shared__ uint32_t s_dyn[];  // [DS_NBK] counters / cursors
     const int tid = threadIdx.x;
+    // The first kernel behind the preprocess pass hands the partial sums of R to the host: plain stores into its pinned buffer
+    // (a copy command of 8 KB costs a 5-us blit kernel on the stream); the event behind this kernel tells the host they are there.
+    if (!EMIT && host_r != nullptr && blockIdx.x == 0 && tid < R_SLOTS) host_r[tid * R_SLOT_STRIDE] = r_slots[tid * R_SLOT_STRIDE];
     const DepthMap dm = depth_map(r_slots);
     uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * DS_NBK;  // slices of one XCD adjacent (binning.h)
     for (int b = tid; b < DS_NBK; b += 1024) s_dyn[b] = EMIT ? ranges[b].x + my_partial[b] : 0u;

@@ -122,13 +122,15 @@ DepthScratch depth_scratch(char* base, int P)
 constexpr int MAX_DEVICES = 64;
 struct HostSync {
     int* pinned = nullptr;   // R partial sums, then {R, longest tile list} of the range scan
+    int* pinned_dev = nullptr;  // the same buffer as the kernels address it (they store into it directly)
     hipEvent_t ev = nullptr;
     hipEvent_t ev2 = nullptr;
     bool ok = false;
     bool init()
     {
         if (ok) return true;
-        if (hipHostMalloc((void**)&pinned, (R_SLOTS * R_SLOT_STRIDE + 4) * sizeof(int), hipHostMallocDefault) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&pinned, (R_SLOTS * R_SLOT_STRIDE + 4) * sizeof(int), hipHostMallocMapped) != hipSuccess) return false;
+        if (hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess) return false;
         ok = true;
@@ -380,11 +382,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             g_attr_set[dev].store(true, std::memory_order_release);
         }
     }
-    // R is known after the preprocess pass; its copy to the host overlaps the depth sort and the counting passes.
+    // R is known after the preprocess pass; the first kernel of the depth sort stores its partial sums into the host's pinned
+    // buffer, and the host reads them while the depth sort and the counting passes run.
     if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host buffer / event");
-    HIP_TRY(hipMemcpyAsync(g_host_sync.pinned, img.num_rendered, R_SLOTS * R_SLOT_STRIDE * sizeof(int),
-                           hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
     {
         StageTimer t(stream, MI_STAGE_DEPTH_SORT);
         // depth ordering -> sorted_idx[rank] and the per-rank geometry records (depth_sort.h): 6 launches
@@ -398,7 +398,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         const int idx_passes = (idx_bits + 7) / 8;
         hipLaunchKernelGGL(depth_bucket_kernel<false>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
                            geom.depth_key, ds.partial, (const uint2*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (BlendRec*)nullptr,
-                           (const int*)img.num_rendered);
+                           (const int*)img.num_rendered, g_host_sync.pinned_dev);
+        HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
         hipLaunchKernelGGL(scan_partials_kernel, dim3((DS_NBK + 63) / 64), dim3(1024), 0, stream, DS_NBK, nwg_d, ds.partial, ds.total);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), (DS_NBK + 1) * sizeof(uint32_t), stream, DS_NBK, ds.total, ds.ranges, ds.out2,
                            (uint32_t)DS_WAVE, DS_NB, ds.big_list);
@@ -439,11 +440,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)ntiles + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
-                           img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr);
+                           img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr,
+                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE);
     }
     STAGE_CHECK("tile scan");
-    HIP_TRY(hipMemcpyAsync(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE, img.num_rendered + R_SLOTS * R_SLOT_STRIDE,
-                           2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(g_host_sync.ev2, stream));
     // rasterizer_impl.cu:280-281: the host needs num_rendered to size the binning buffer.  We wait only for
     // the copy (event), not for the work queued behind it.
