@@ -371,12 +371,17 @@ def _make_plain(channels):
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
+            # autograd would otherwise hand backward a zero-filled int32 (P,) "gradient" for radii on every call (a 4-MB fill)
+            ctx.set_materialize_grads(False)
+            ctx.out_shape = tuple(color.shape)
             return color, radii
 
         @staticmethod
         def backward(ctx, grad_out_color, _):
             num_rendered = ctx.num_rendered
             rs = ctx.raster_settings
+            if grad_out_color is None:   # the image was not used: what autograd would have materialised
+                grad_out_color = torch.zeros(ctx.out_shape, dtype=torch.float32, device=ctx.saved_tensors[1].device)
             (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
              imgBuffer) = ctx.saved_tensors
             args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -480,12 +485,19 @@ def _make_depth():
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
+            ctx.set_materialize_grads(False)   # see the plain variant: no zero-filled "gradients" for radii / unused outputs
+            ctx.out_shapes = (tuple(color.shape), tuple(out_mask.shape))
             return color, out_mask, depth, radii
 
         @staticmethod
         def backward(ctx, grad_out_color, grad_out_mask, grad_out_depth, _):
             num_rendered = ctx.num_rendered
             rs = ctx.raster_settings
+            dev_ = ctx.saved_tensors[1].device
+            if grad_out_color is None:
+                grad_out_color = torch.zeros(ctx.out_shapes[0], dtype=torch.float32, device=dev_)
+            if grad_out_mask is None:
+                grad_out_mask = torch.zeros(ctx.out_shapes[1], dtype=torch.float32, device=dev_)
             (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
              imgBuffer) = ctx.saved_tensors
             args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -532,11 +544,15 @@ def _make_depth():
             ctx.save_for_backward(means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, radii, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
+            ctx.set_materialize_grads(False)
+            ctx.out_shape = tuple(out_mask.shape)
             return out_mask, radii
 
         @staticmethod
         def backward(ctx, grad_out_mask, _):
             rs = ctx.raster_settings
+            if grad_out_mask is None:
+                grad_out_mask = torch.zeros(ctx.out_shape, dtype=torch.float32, device=ctx.saved_tensors[0].device)
             (means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, radii, geomBuffer, binningBuffer,
              imgBuffer) = ctx.saved_tensors
             grad_mask = rasterize_mask_gaussians_backward_native(means3D, grad_out_mask, geomBuffer, ctx.num_rendered,

@@ -216,6 +216,17 @@ def test_depth_package_mask_contract():
         grads.append(mask.grad.reshape(-1).clone())
     hp.assert_close("dL_dmask (P,1) vs (P,)", grads[1].cpu().numpy(), grads[0].cpu().numpy(), rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
     assert float(grads[0].abs().max()) > 0
+    # outputs the loss does not use arrive in backward as None (the Functions switch autograd's zero materialisation off: it
+    # would fill an int32 (P,) "gradient" for radii on every call): a loss on out_mask alone / on the image alone still works
+    mask = t(inp.mask).reshape(3000, 1).requires_grad_(True)
+    color, omask, depth, radii = rast(mask=mask, **kw)
+    (omask.sum() * 0.5).backward()
+    hp.assert_close("dL_dmask, image unused", mask.grad.reshape(-1).cpu().numpy(), grads[0].cpu().numpy(), rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
+    mask = t(inp.mask).reshape(3000, 1).requires_grad_(True)
+    cols = t(inp.colors_precomp).requires_grad_(True)
+    color, omask, depth, radii = rast(mask=mask, **dict(kw, colors_precomp=cols))
+    color.sum().backward()
+    assert float(cols.grad.abs().max()) > 0 and not bool(mask.grad.any())
 
 
 def test_bench_single_rank_rccl_step():
