@@ -95,7 +95,7 @@ int mi_rast_forward(
     float* out_depth,       /* [H, W]  (DEPTH variant) */
     int* radii,             /* [P] */
     int debug,
-    int flags,                    /* MI_RAST_FULL_LISTS | MI_RAST_F32_BLEND; `debug` implies MI_RAST_FULL_LISTS */
+    int flags,                    /* MI_RAST_* bits above (0 = product default); `debug` implies MI_RAST_FULL_LISTS */
     void* features_ready_event,   /* hipEvent_t or NULL: see "List modes and the features-ready event" below */
     void* stream,
     int* num_rendered /* [host] */);
