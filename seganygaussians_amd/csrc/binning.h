@@ -41,13 +41,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
     return v;
 }
 
-// Item of workgroup b of an n-workgroup grid such that the workgroups of one XCD (b % 8) own a contiguous run of items.
-__device__ __forceinline__ uint32_t xcd_block_item(uint32_t b, uint32_t n)
-{
-    const uint32_t x = b & 7u, j = b >> 3, base = n >> 3, rem = n & 7u;
-    return x * base + min(x, rem) + j;
-}
-
 // Row of partial[][] (= position of the slice inside every tile's segment) of workgroup b.  Workgroup b runs on XCD b % 8
 // (tools/xcc_probe.hip) and each XCD has its own L2: with the slices of one XCD next to each other, the 4-byte entries that
 // share a 128-byte line of a tile's segment are mostly stored from ONE XCD instead of eight (measured: emit 0.086 -> 0.074 ms;
@@ -764,7 +757,8 @@ __device__ __forceinline__ void emit_blend_list(SrcPtr sorted_entries, int m, ui
 }
 
 template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT, bool FULL = true>
-__global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ entries,
+__global__ void __launch_bounds__(NT) tile_sort_kernel(uint32_t ntiles, const uint2* __restrict__ ranges,
+                                                        uint32_t* __restrict__ entries,
                                                         uint32_t* __restrict__ scratch,
                                                         const uint32_t* __restrict__ sorted_idx,
                                                         const BlendRec* __restrict__ rank_rec,
@@ -778,9 +772,11 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__
     __shared__ uint32_t s_hist[NW][256];
     __shared__ uint32_t s_wcount[NW];
     const int tid = threadIdx.x;
-    // workgroup b runs on XCD b % 8: each XCD sorts a contiguous eighth of the tiles, so the rank records that neighbouring
-    // tiles share are gathered through one L2
-    const uint32_t tile = xcd_block_item(blockIdx.x, gridDim.x);
+    // (tile = workgroup id: neighbouring tiles on different XCDs.  Contiguous runs per XCD -- common.h -- save 3 % here through
+    // the rank records neighbouring tiles share, but the cost of a tile is its list length, and a static split would let a
+    // scene's dense half wait for two of the eight XCDs.)
+    const uint32_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     if (LO == 0 && n == 0 && tid == 0) blend_count[tile] = 0u;

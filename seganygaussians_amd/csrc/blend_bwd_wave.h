@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     const float* __restrict__ colors, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dout_mask,
     float* __restrict__ gpack /*[P,8] packed field gradients*/, float* __restrict__ dL_dcolors,
+    uint32_t* __restrict__ queue_ctr /* eight zeroed work-queue counters (common.h: xcd_grab) */,
     int ablate /* timing experiments: profiling build only (common.h: MI_ABLATE) */)
 {
     constexpr int FROW = BwvCfg<C>::FROW, QCAP = BwvCfg<C>::QCAP, FEAT4 = BwvCfg<C>::FEAT4;
@@ -66,13 +67,9 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     float4* const s_wu4 = s_wu4_[wv];
     uint2* const s_queue = s_queue_[wv];
 
-    // blockIdx -> (tile, quadrant): the four quadrants of a tile get block ids that are congruent modulo 8 (workgroups are
-    // dealt round robin over the 8 XCDs) and adjacent in dispatch order.
-    const uint32_t b = blockIdx.x;
-    const uint32_t xcd = b & 7u, jj = b >> 3;
-    const uint32_t quad = WPB == 1 ? (jj & 3u) : (uint32_t)(threadIdx.x >> 6);
-    const uint32_t tile = WPB == 1 ? (jj >> 2) * 8u + xcd : b;
-    if (tile >= ntiles) return;
+    // One (tile, quadrant) item: everything below.  With one wave per workgroup (the product) a wave works through items it
+    // takes from the queue of the XCD it runs on (see the end of the kernel).
+    auto quadrant = [&](const uint32_t tile, const uint32_t quad) __attribute__((always_inline)) {
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
 
     const int lane = threadIdx.x & 63;
@@ -517,6 +514,29 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
         atomicAdd(&gpack[8 * 12 + 7], 1.f);
     }
 #undef TK
+    };
+
+    if (WPB == 1) {
+        // workgroup -> (tile, quadrant).  Every XCD works through a contiguous run of tiles (common.h: xcd_tile), and the four
+        // quadrants of a tile go to four of its waves at about the same time: the records, the feature rows and the gradient
+        // lines that the quadrants of a tile AND neighbouring tiles share stay in one L2.  The first three quarters of a run
+        // are assigned by the workgroup id (id = 8 (4 j + quad) + x: XCD x, j-th tile of its run); the items of the last
+        // quarter are TAKEN from the XCD's queue, and from the other XCDs' queues when that one is empty (xcd_grab): the
+        // runs stay contiguous while the XCDs keep pace, and nobody idles when the scene's density does not let them.
+        const uint32_t b = blockIdx.x, nstatic = 32u * xcd_static_len(ntiles);
+        uint32_t item;
+        if (b < nstatic) {
+            const uint32_t x = b & 7u, jj = b >> 3;
+            const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
+            // (an XCD whose static part is shorter than the longest one leaves its last ids without an item)
+            item = (jj >> 2) < len - len / 4u ? 4u * start + jj : 0xFFFFFFFFu;
+        } else {
+            item = xcd_grab(queue_ctr, ntiles, 4u);
+        }
+        if (item != 0xFFFFFFFFu) quadrant(item >> 2, item & 3u);
+    } else if (blockIdx.x < ntiles) {
+        quadrant(blockIdx.x, (uint32_t)(threadIdx.x >> 6));
+    }
 }
 
 }  // namespace mirast

@@ -164,6 +164,54 @@ __device__ __forceinline__ float gauss_exp(float power)
     }
 }
 
+// ---- workgroup -> tile ----------------------------------------------------------------------------------------------------
+// Workgroup b of a 1-D grid runs on XCD b % 8 (tools/xcc_probe.hip), and every XCD has its own L2.  Neighbouring tiles share most
+// of their Gaussians.  The backward blend therefore gives every XCD a CONTIGUOUS run of tiles (row major:
+// an eighth of the image, a band of whole tile rows): the records and feature rows neighbouring tiles share come through one L2,
+// and the gradient atomics of a Gaussian hit lines that L2 already holds instead of lines that travel between L2s -- backward
+// blend 0.647 -> 0.565 ms on cfg3.
+//   static:              workgroup id = 8 j + x is the j-th tile of XCD x's run.  The kernel time is then the busiest XCD's.
+//   dynamic (xcd_grab):  the backward blend's cost per tile is the scene's density, and a static split would hand one XCD the
+//                        empty sky.  There the last quarter of every run is a QUEUE: a wave takes its item from the queue of
+//                        the XCD it runs on (one returning atomic on that XCD's counter; HW_REG_XCC_ID says which) and, when
+//                        that is empty, from the next XCD's.  As many such waves as queued items, each takes exactly one:
+//                        every item is taken exactly once.  (All of a run queued: 0.597 ms instead of 0.565 -- the counter's
+//                        answer is a round trip in front of every wave's work; persistent waves that request the next item
+//                        ahead of time: 0.63, spills and an uneven tail.)
+__device__ __forceinline__ uint32_t xcd_run_start(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * n) >> 3); }
+constexpr int XCD_QUEUE_STRIDE = 16;  // uint32 words between the eight queue counters (one 64-byte line each)
+// The queued part of XCD x's run: its last quarter (len / 4 tiles).  xcd_static_len: the longest static part of any run.
+__host__ __device__ inline uint32_t xcd_static_len(uint32_t n)
+{
+    const uint32_t longest = (n + 7u) >> 3;
+    return longest - longest / 4u;
+}
+__host__ __device__ inline uint32_t xcd_queued_tiles(uint32_t n)
+{
+    uint32_t q = 0;
+    for (uint32_t x = 0; x < 8u; x++) {
+        const uint32_t len = (uint32_t)(((uint64_t)(x + 1u) * n) >> 3) - (uint32_t)(((uint64_t)x * n) >> 3);
+        q += len / 4u;
+    }
+    return q;
+}
+// Takes one queued item (per items per tile, consecutive: e.g. the four quadrants); wave-uniform; 0xFFFFFFFF when every queue is
+// empty (cannot happen with exactly per * xcd_queued_tiles(n) takers).  counters: eight zeroed words, XCD_QUEUE_STRIDE apart.
+__device__ __forceinline__ uint32_t xcd_grab(uint32_t* __restrict__ counters, uint32_t n, uint32_t per)
+{
+    const uint32_t x0 = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
+    const bool first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;
+    for (uint32_t k = 0; k < 8u; k++) {
+        const uint32_t x = (x0 + k) & 7u;
+        const uint32_t start = xcd_run_start(x, n), len = xcd_run_start(x + 1u, n) - start;
+        uint32_t got = 0;
+        if (first) got = atomicAdd(&counters[x * XCD_QUEUE_STRIDE], 1u);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (got < (len / 4u) * per) return (start + len - len / 4u) * per + got;
+    }
+    return 0xFFFFFFFFu;
+}
+
 // ---- wave64 helpers -------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 

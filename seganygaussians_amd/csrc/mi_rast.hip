@@ -492,11 +492,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
 #define LAUNCH_TILE_SORT(LO, CAP, FB, NT)                                                                                 \
     do {                                                                                                                  \
         if (full)                                                                                                         \
-            hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT, true>), dim3(ntiles), dim3(NT), 0, stream, img.ranges,  \
+            hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT, true>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges,  \
                                bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,          \
                                bin.blend_rec, img.blend_count);                                                           \
         else                                                                                                              \
-            hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT, false>), dim3(ntiles), dim3(NT), 0, stream, img.ranges, \
+            hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT, false>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges, \
                                bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,          \
                                bin.blend_rec, img.blend_count);                                                           \
     } while (0)
@@ -759,7 +759,7 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_INDEX_REC] = c.take(p * sizeof(BlendRec));
     off[MI_GEOM_SORTED_IDX] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_SORT_TEMP] = c.take(depth_sort_temp_bytes(P) + 16);
-    off[MI_GEOM_BWD_PACK] = c.take(p * 8 * sizeof(float));
+    off[MI_GEOM_BWD_PACK] = c.take(p * 8 * sizeof(float) + 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t));  // + the backward's work-queue counters
     off[MI_GEOM_RANK_REC] = c.take(p * sizeof(BlendRec));
     return c.off;
 }
@@ -892,16 +892,17 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     const float* color_ptr = (colors_precomp != nullptr) ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:389
     {
         StageTimer t(stream, MI_STAGE_BLEND_BWD);
-        HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float), stream));
+        HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float) + 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t), stream));
+        uint32_t* queue_ctr = reinterpret_cast<uint32_t*>(geom.bwd_pack + (size_t)P * 8);
 #define LAUNCH_BWD_MFMA(...)                                                                                              \
     hipLaunchKernelGGL((blend_bwd_mfma_kernel<__VA_ARGS__>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,    \
                        bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib, dL_dpix, \
                        dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
         const uint32_t nt_ = vp.grid_x * vp.grid_y;
 #define LAUNCH_BWD_WAVE_(WPB, XE, ...)                                                                                    \
-    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE>), dim3(WPB == 1 ? ((nt_ + 7u) / 8u) * 32u : nt_), dim3(64 * WPB), 0, \
+    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE>), dim3(WPB == 1 ? 32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_) : nt_), dim3(64 * WPB), 0,    \
                        stream, img.ranges, bin.blend_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, background, color_ptr, \
-                       img.final_T, img.n_contrib, dL_dpix, dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
+                       img.final_T, img.n_contrib, dL_dpix, dL_dout_mask, geom.bwd_pack, dL_dcolor, queue_ctr, g_ablate)
 #ifdef MI_RAST_PROFILING
 #define LAUNCH_BWD_WAVE(...)                                                    \
     do {                                                                        \
