@@ -1,8 +1,9 @@
 # Bench lines of the current build for profiles/<tag>_bench_lines.md (run on the GPU box through gpurun).
-TAG=${1:-r02e}
+TAG=${1:-r02f}
 OUT=gpurun_out/lines_$TAG
 mkdir -p $OUT
-python bench.py --ref-on-gpu > $OUT/cfg3.log 2>&1
+python bench.py > $OUT/cfg3_default.log 2>&1
+python bench.py --ref-on-gpu --steps 30 > $OUT/cfg3.log 2>&1
 python bench.py --config cfg2 > $OUT/cfg2.log 2>&1
 python bench.py --config cfg5 --ref-on-gpu > $OUT/cfg5.log 2>&1
 python bench.py --config cfg1 > $OUT/cfg1.log 2>&1
