@@ -517,11 +517,11 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     };
 
     if (WPB == 1) {
-        // workgroup -> (tile, quadrant).  Every XCD works through a contiguous run of tiles (common.h: xcd_tile), and the four
+        // workgroup -> (tile, quadrant).  Every XCD works through a contiguous run of tiles (common.h), and the four
         // quadrants of a tile go to four of its waves at about the same time: the records, the feature rows and the gradient
-        // lines that the quadrants of a tile AND neighbouring tiles share stay in one L2.  The first three quarters of a run
-        // are assigned by the workgroup id (id = 8 (4 j + quad) + x: XCD x, j-th tile of its run); the items of the last
-        // quarter are TAKEN from the XCD's queue, and from the other XCDs' queues when that one is empty (xcd_grab): the
+        // lines that the quadrants of a tile AND neighbouring tiles share stay in one L2.  The first half of a run
+        // is assigned by the workgroup id (id = 8 (4 j + quad) + x: XCD x, j-th tile of its run); the items of the second
+        // half are TAKEN from the XCD's queue, and from the other XCDs' queues when that one is empty (xcd_grab): the
         // runs stay contiguous while the XCDs keep pace, and nobody idles when the scene's density does not let them.
         const uint32_t b = blockIdx.x, nstatic = 32u * xcd_static_len(ntiles);
         uint32_t item;
@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             const uint32_t x = b & 7u, jj = b >> 3;
             const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
             // (an XCD whose static part is shorter than the longest one leaves its last ids without an item)
-            item = (jj >> 2) < len - len / 4u ? 4u * start + jj : 0xFFFFFFFFu;
+            item = (jj >> 2) < len - len / XCD_QUEUE_DIV ? 4u * start + jj : 0xFFFFFFFFu;
         } else {
             item = xcd_grab(queue_ctr, ntiles, 4u);
         }

@@ -172,7 +172,7 @@ __device__ __forceinline__ float gauss_exp(float power)
 // blend 0.647 -> 0.565 ms on cfg3.
 //   static:              workgroup id = 8 j + x is the j-th tile of XCD x's run.  The kernel time is then the busiest XCD's.
 //   dynamic (xcd_grab):  the backward blend's cost per tile is the scene's density, and a static split would hand one XCD the
-//                        empty sky.  There the last quarter of every run is a QUEUE: a wave takes its item from the queue of
+//                        empty sky.  There the second half of every run is a QUEUE: a wave takes its item from the queue of
 //                        the XCD it runs on (one returning atomic on that XCD's counter; HW_REG_XCC_ID says which) and, when
 //                        that is empty, from the next XCD's.  As many such waves as queued items, each takes exactly one:
 //                        every item is taken exactly once.  (All of a run queued: 0.597 ms instead of 0.565 -- the counter's
@@ -180,18 +180,21 @@ __device__ __forceinline__ float gauss_exp(float power)
 //                        ahead of time: 0.63, spills and an uneven tail.)
 __device__ __forceinline__ uint32_t xcd_run_start(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * n) >> 3); }
 constexpr int XCD_QUEUE_STRIDE = 16;  // uint32 words between the eight queue counters (one 64-byte line each)
-// The queued part of XCD x's run: its last quarter (len / 4 tiles).  xcd_static_len: the longest static part of any run.
+constexpr uint32_t XCD_QUEUE_DIV = 2;  // the queued part of a run is its last 1 / XCD_QUEUE_DIV
+// The queued part of XCD x's run: its last len / XCD_QUEUE_DIV tiles.  xcd_static_len: the longest static part of any run.
+// (Half of the run: when half of the XCDs have nothing of their own to do -- a scene that fills half of the image -- the idle
+// half takes exactly the queued halves of the busy ones, and all finish together.  A quarter measured the same on cfg3.)
 __host__ __device__ inline uint32_t xcd_static_len(uint32_t n)
 {
     const uint32_t longest = (n + 7u) >> 3;
-    return longest - longest / 4u;
+    return longest - longest / XCD_QUEUE_DIV;
 }
 __host__ __device__ inline uint32_t xcd_queued_tiles(uint32_t n)
 {
     uint32_t q = 0;
     for (uint32_t x = 0; x < 8u; x++) {
         const uint32_t len = (uint32_t)(((uint64_t)(x + 1u) * n) >> 3) - (uint32_t)(((uint64_t)x * n) >> 3);
-        q += len / 4u;
+        q += len / XCD_QUEUE_DIV;
     }
     return q;
 }
@@ -207,7 +210,7 @@ __device__ __forceinline__ uint32_t xcd_grab(uint32_t* __restrict__ counters, ui
         uint32_t got = 0;
         if (first) got = atomicAdd(&counters[x * XCD_QUEUE_STRIDE], 1u);
         got = __builtin_amdgcn_readfirstlane(got);
-        if (got < (len / 4u) * per) return (start + len - len / 4u) * per + got;
+        if (got < (len / XCD_QUEUE_DIV) * per) return (start + len - len / XCD_QUEUE_DIV) * per + got;
     }
     return 0xFFFFFFFFu;
 }

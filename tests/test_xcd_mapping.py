@@ -4,6 +4,8 @@ the statically assigned ids and the queued items together cover every (tile, qua
 contiguous run, and the grid the host launches has exactly one workgroup per queued item behind the static ids."""
 import numpy as np
 
+QUEUE_DIV = 2   # common.h: XCD_QUEUE_DIV
+
 
 def run_start(x, n):
     return (x * n) >> 3
@@ -11,11 +13,11 @@ def run_start(x, n):
 
 def static_len(n):
     longest = (n + 7) >> 3
-    return longest - longest // 4
+    return longest - longest // QUEUE_DIV
 
 
 def queued_tiles(n):
-    return sum((run_start(x + 1, n) - run_start(x, n)) // 4 for x in range(8))
+    return sum((run_start(x + 1, n) - run_start(x, n)) // QUEUE_DIV for x in range(8))
 
 
 def assignment(n):
@@ -25,12 +27,12 @@ def assignment(n):
     for b in range(nstatic):
         x, jj = b & 7, b >> 3
         start, length = run_start(x, n), run_start(x + 1, n) - run_start(x, n)
-        if (jj >> 2) < length - length // 4:
+        if (jj >> 2) < length - length // QUEUE_DIV:
             static.append(4 * start + jj)
     queued = []
     for x in range(8):
         start, length = run_start(x, n), run_start(x + 1, n) - run_start(x, n)
-        q = length // 4
+        q = length // QUEUE_DIV
         queued += [(start + length - q) * 4 + got for got in range(4 * q)]
     return static, queued, nstatic + 4 * queued_tiles(n)
 
@@ -46,7 +48,7 @@ def test_every_quadrant_exactly_once():
         for b in range(0, 32 * static_len(n), 97):
             x, jj = b & 7, b >> 3
             start, length = run_start(x, n), run_start(x + 1, n) - run_start(x, n)
-            if (jj >> 2) < length - length // 4:
+            if (jj >> 2) < length - length // QUEUE_DIV:
                 assert start <= (4 * start + jj) >> 2 < start + length
 
 
