@@ -6,13 +6,16 @@ metric : train views/sec (fwd+bwd), 1080p, 1M Gaussians, 32-D features  (BASELIN
          feature gradient).
 step   : ONE forward + backward of the rasterizer hot path over one synthetic view, through the
          drop-in Python API (GaussianRasterizer -> autograd backward), inputs resident in HBM.
-         Every allocation, zero-fill and the num_rendered host sync are inside the timed region.
+         Every allocation, zero-fill and the num_rendered host read-back are inside the timed region.
 
 Usage:  python bench.py [--gpus N --steps K --warmup W] [--config cfg3|cfg5|cfg2|cfg1]
         N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
                 --master-port P bench.py --gpus N --steps K --warmup W
         cfg2 = BASELINE config 2: 1M Gaussians, 1080p, SH degree 3 RGB + mask + depth, FORWARD only, through the
         diff_gaussian_rasterization_depth drop-in; cfg5 = 5M Gaussians, 1600x1063, 64-D, fwd+bwd.
+        Defaults: N = 1, K = 100 timed steps, W = 10 warm-up steps behind untimed settling blocks (--settle seconds, see
+        main()); the whole default run, CPU baseline and parity check included, takes about half a minute.
+        --fast-exp / --ref-on-gpu / --dist-single: reporting and testing aids (see their help texts).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) formula) / its
