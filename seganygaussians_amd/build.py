@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_rast.so")
 SRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["mi_rast.hip", "common.h", "cull.h", "geometry.h", "binning.h", "depth_sort.h", "knn_smooth.h", "knn.h", "blend_fwd.h", "blend_fwd_x3.h", "blend_bwd.h", "blend_bwd_mfma.h", "blend_bwd_wave.h"]
+SOURCES = ["mi_rast.hip", "common.h", "cull.h", "geometry.h", "binning.h", "depth_sort.h", "knn_smooth.h", "knn.h", "blend_fwd.h", "blend_fwd_x3.h", "blend_bwd.h", "blend_bwd_mfma.h", "blend_bwd_shared.h", "blend_bwd_wave.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "mi_rast.h")
 
 # -ffp-contract=off is part of the numeric contract: the geometry path that feeds the

@@ -23,14 +23,11 @@
 // Staging (records, feature rows) is per batch of RB2 records; for C = 32 it is pipelined over the batches (BwdCfg::PIPE).
 #pragma once
 
+#include "blend_bwd_shared.h"
 #include "blend_fwd.h"
 #include "common.h"
 
 namespace mirast {
-
-constexpr int WROW = 68;   // padded w/u row (floats)
-constexpr int CHK = 16;    // rows per MFMA chunk
-constexpr int DLROW = 33;  // padded gradient-image staging row (floats; 32 channels at a time)
 
 // Per channel count: blend-list records per batch (LDS budget of 3 workgroups per CU at C = 32, 2 at C = 64),
 // padded feature row (floats; conflict-free 16-lane b128 operand reads), waves per SIMD the registers allow.
@@ -48,14 +45,6 @@ struct BwdCfg {
     static constexpr bool PIPE = C == 32;
     static_assert(POOL4 * 4 >= 4 * 64 * DLROW, "gradient-image staging must fit in the aliased buffers");
     static_assert(RB2 + FROW / 4 <= 256, "staging roles are assigned by thread index");
-};
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// One staged record: {x, y, -a/2, -b} {-c/2, opacity, list position << 4 | quadrant mask (int bits), Gaussian id (int bits)} with the conic
-// (a, b, c) pre-scaled to (-a/2, -b, -c/2) for gauss_power (common.h).
-struct BwdPar {
-    float4 q0, q1;
 };
 
 // VALU issue is the limiter of this kernel: a wave issues one VALU instruction per ~8 cycles, a SIMD reaches

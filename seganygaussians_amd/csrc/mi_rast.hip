@@ -20,7 +20,9 @@
 #include "knn_smooth.h"
 #include "knn.h"
 #include "blend_bwd.h"
-#include "blend_bwd_mfma.h"
+#ifdef MI_RAST_PROFILING
+#include "blend_bwd_mfma.h"  // round 1's tile-batched kernel: A/B comparisons only (MI_RAST_ABLATE=2048)
+#endif
 #include "blend_bwd_wave.h"
 #include "blend_fwd.h"
 #include "blend_fwd_x3.h"

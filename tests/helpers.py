@@ -25,7 +25,12 @@ def make_inputs(P, W, H, C, seed=0, *, focal=None, log_scale=None, log_scale_std
     focal = focal or 0.85 * W
     log_scale = math.log(0.05) if log_scale is None else log_scale
     sc = scenes.make_scene(P, W, H, focal, C, log_scale, log_scale_std, seed=seed, with_shs=with_shs, z_range=z_range)
-    cam = scenes.look_at_camera(W, H, focal) if camera == "front" else scenes.orbit_camera(W, H, focal, 0.2, 0.07)
+    if camera == "front":
+        cam = scenes.look_at_camera(W, H, focal)
+    elif camera == "orbit":
+        cam = scenes.orbit_camera(W, H, focal, 0.2, 0.07)
+    else:  # ("orbit", angle, tilt): e.g. the pose bench.py gives rank r of BASELINE config 4, (0.05 r, 0.02 r)
+        cam = scenes.orbit_camera(W, H, focal, float(camera[1]), float(camera[2]))
     rng = np.random.default_rng(seed + 1000)
     if bg is None:
         bg = np.zeros(C, np.float32)
@@ -53,12 +58,17 @@ def make_inputs(P, W, H, C, seed=0, *, focal=None, log_scale=None, log_scale_std
                      cov3D_precomp=cov, mask=mask)
 
 
-def inputs_from_config(name, P=None, seed=0, with_shs=False, use_mask=False):
+def inputs_from_config(name, P=None, seed=0, with_shs=False, use_mask=False, camera="front"):
     c = scenes.CONFIGS[name]
     inp = make_inputs(c["P"] if P is None else P, c["W"], c["H"], c["C"], seed, focal=c["focal"],
                       log_scale=c["ls_mean"], log_scale_std=c["ls_std"], with_shs=with_shs,
-                      sh_degree=3 if with_shs else 0, use_mask=use_mask)
+                      sh_degree=3 if with_shs else 0, use_mask=use_mask, camera=camera)
     return inp
+
+
+def rank_camera(rank):
+    """The pose bench.py gives rank `rank` of BASELINE config 4 (8 orbit poses over the same Gaussians; rank 0 = front view)."""
+    return "front" if rank == 0 else ("orbit", 0.05 * rank, 0.02 * rank)
 
 
 # ---------------------------------------------------------------------------------------------------
