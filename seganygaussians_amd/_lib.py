@@ -23,6 +23,7 @@ EXPORTS = [
     "mi_rast_profile_enable", "mi_rast_profile_read",
     "mi_knn_smooth_forward", "mi_knn_smooth_backward",  # include/mi_knn_smooth.h
     "mi_knn_workspace_bytes", "mi_knn_build", "mi_knn_query", "mi_knn_mean_dist2",  # include/mi_knn.h
+    "mi_contrastive_forward", "mi_contrastive_backward",  # include/mi_contrastive.h
 ]
 
 _lib = None
@@ -93,6 +94,10 @@ def load():
     L.mi_knn_query.argtypes = [i, vp, i, vp, i, i, vp, vp, vp]
     L.mi_knn_mean_dist2.restype = i
     L.mi_knn_mean_dist2.argtypes = [i, vp, vp, C.c_size_t, vp, vp]
+    L.mi_contrastive_forward.restype = i
+    L.mi_contrastive_forward.argtypes = [i, i, i, vp, i, i, i, vp, i, vp, vp, vp, vp, vp, vp, vp]
+    L.mi_contrastive_backward.restype = i
+    L.mi_contrastive_backward.argtypes = [i, i, i, vp, i, i, i, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -12,8 +12,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_rast.so")
 SRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["mi_rast.hip", "common.h", "cull.h", "geometry.h", "binning.h", "depth_sort.h", "knn_smooth.h", "knn.h", "blend_fwd.h", "blend_fwd_x3.h", "blend_bwd.h", "blend_bwd_mfma.h", "blend_bwd_shared.h", "blend_bwd_wave.h"]
+SOURCES = ["mi_rast.hip", "common.h", "cull.h", "geometry.h", "binning.h", "depth_sort.h", "knn_smooth.h", "knn.h", "blend_fwd.h", "blend_fwd_x3.h", "blend_bwd.h", "blend_bwd_mfma.h", "blend_bwd_shared.h", "blend_bwd_wave.h", "contrastive.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "mi_rast.h")
+HEADERS = [os.path.join(os.path.dirname(_HERE), "include", h) for h in ("mi_rast.h", "mi_knn.h", "mi_knn_smooth.h", "mi_contrastive.h")]
 
 # -ffp-contract=off is part of the numeric contract: the geometry path that feeds the
 # integer tile/sort results must round every binary32 op separately, like the oracle.
@@ -32,7 +33,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(SRC_DIR, s) for s in SOURCES] + [HEADER]
+    deps = [os.path.join(SRC_DIR, s) for s in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 

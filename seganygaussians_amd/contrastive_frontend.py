@@ -52,3 +52,82 @@ def sample_scale_conditioned_features(rendered_features: torch.Tensor, out_hw, s
     rays = (top * (1 - ly) + bot * ly).transpose(0, 1)               # (S, C)
     scaled = rays.unsqueeze(0) * gates.unsqueeze(1)                  # (N, S, C)
     return torch.nn.functional.normalize(scaled, dim=-1, p=2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The HIP path (include/mi_contrastive.h, csrc/contrastive.h): regulariser + rays, forward and backward
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+class _ContrastiveFrontEnd(torch.autograd.Function):
+    """(rendered (C,h,w), gates (N,C)) -> (out (N,S,C), rendered_feature_norm ()) through mi_contrastive_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, rendered, gates, ray_yx, H, W):
+        from . import _lib
+        if not rendered.is_cuda:
+            raise RuntimeError("contrastive_front_end needs GPU tensors: the front end has no CPU fallback "
+                               "(sample_scale_conditioned_features is the PyTorch restatement the tests compare with)")
+        L = _lib.load()
+        rendered = rendered.contiguous().float()
+        gates_c = gates.contiguous().float()
+        C, h, w = rendered.shape
+        N, S = gates_c.shape[0], ray_yx.shape[0]
+        dev = rendered.device
+        out = torch.empty((N, S, C), device=dev, dtype=torch.float32)
+        ray_feat = torch.empty((S, C), device=dev, dtype=torch.float32)
+        inv_len = torch.empty((N, S), device=dev, dtype=torch.float32)
+        inv_norm = torch.empty((h * w,), device=dev, dtype=torch.float32)
+        norm_sum = torch.zeros((1,), device=dev, dtype=torch.float64)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.mi_contrastive_forward(C, h, w, rendered.data_ptr(), int(H), int(W), S, _ptr(ray_yx), N, gates_c.data_ptr(),
+                                      _ptr(out), _ptr(ray_feat), _ptr(inv_len), inv_norm.data_ptr(), norm_sum.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(_lib.last_error())
+        ctx.save_for_backward(rendered, gates_c, ray_yx, out, ray_feat, inv_len, inv_norm)
+        ctx.dims = (C, h, w, int(H), int(W), S, N)
+        return out, (norm_sum[0] / float(h * w)).float()
+
+    @staticmethod
+    def backward(ctx, d_out, d_norm):
+        from . import _lib
+        L = _lib.load()
+        rendered, gates_c, ray_yx, out, ray_feat, inv_len, inv_norm = ctx.saved_tensors
+        C, h, w, H, W, S, N = ctx.dims
+        dev = rendered.device
+        d_rendered = torch.empty_like(rendered)
+        d_gates = torch.zeros_like(gates_c)
+        d_out_c = None if d_out is None else d_out.contiguous().float()
+        if d_out_c is None and S > 0:
+            d_out_c = torch.zeros((N, S, C), device=dev, dtype=torch.float32)
+        g = None if d_norm is None else d_norm.reshape(1).contiguous().float()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.mi_contrastive_backward(C, h, w, rendered.data_ptr(), H, W, S, _ptr(ray_yx), N, gates_c.data_ptr(), _ptr(out),
+                                       _ptr(ray_feat), _ptr(inv_len), inv_norm.data_ptr(), _ptr(d_out_c), _ptr(g),
+                                       d_rendered.data_ptr(), d_gates.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(_lib.last_error())
+        return d_rendered, d_gates, None, None, None
+
+
+def contrastive_front_end(rendered_features: torch.Tensor, out_hw, sampled_ray: torch.Tensor, gates: torch.Tensor):
+    """train_contrastive_feature.py:234-254 in one forward launch (and two backward launches) on the MI355X:
+
+        rendered_feature_norm = rendered_features.norm(dim=0, p=2).mean()
+        scale_conditioned     = normalize((interpolate(rendered_features, out_hw)[None] * gates[:, :, None, None])
+                                          [:, :, sampled_ray].permute(0, 2, 1), dim=-1)
+
+    rendered_features (C, h, w) fp32 GPU tensor; out_hw = (H, W) of the SAM masks; sampled_ray bool (H, W) -- or an int (S, 2)
+    tensor of (y, x) ray coordinates in row-major order; gates (N, C).  Returns (scale_conditioned (N, S, C),
+    rendered_feature_norm scalar); both differentiable w.r.t. rendered_features and gates."""
+    H, W = int(out_hw[0]), int(out_hw[1])
+    if sampled_ray.dtype == torch.bool:
+        if sampled_ray.shape != (H, W):
+            raise ValueError(f"sampled_ray has shape {tuple(sampled_ray.shape)}, expected {(H, W)}")
+        ray_yx = torch.nonzero(sampled_ray).to(torch.int32).contiguous()     # row-major == mask-indexing order
+    else:
+        ray_yx = sampled_ray.to(torch.int32).contiguous()
+    return _ContrastiveFrontEnd.apply(rendered_features, gates, ray_yx, H, W)

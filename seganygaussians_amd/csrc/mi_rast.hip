@@ -4,6 +4,7 @@
 #include "../../include/mi_rast.h"
 #include "../../include/mi_knn_smooth.h"
 #include "../../include/mi_knn.h"
+#include "../../include/mi_contrastive.h"
 
 #include <hip/hip_runtime.h>
 
@@ -27,6 +28,7 @@
 #include "blend_fwd.h"
 #include "blend_fwd_x3.h"
 #include "common.h"
+#include "contrastive.h"
 #include "geometry.h"
 
 using namespace mirast;
@@ -659,6 +661,59 @@ int mi_knn_smooth_backward(int P, int C, int K, const int* knn_idx, const int* i
     } else {
         hipLaunchKernelGGL(knn_smooth_bwd_mean_kernel<64>, grid, dim3(256), 0, stream, P, K, knn_idx, mask, 1.0f / (float)k, features, dL_dout, dmean, normalize_out);
         hipLaunchKernelGGL(knn_smooth_bwd_feat_kernel<64>, grid, dim3(256), 0, stream, P, inv_offsets, inv_entries, mask, features, dmean, dL_dfeatures);
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_RAST_OK;
+}
+
+
+// ---- contrastive-loss front end (mi_contrastive.h, contrastive.h) --------------------------------------------------------
+int mi_contrastive_forward(int C, int h, int w, const float* rendered, int H, int W, int S, const int* ray_yx, int N,
+                           const float* gates, float* out, float* ray_feat, float* inv_len, float* inv_norm,
+                           double* norm_sum, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C < 1 || h < 1 || w < 1 || H < 1 || W < 1 || S < 0 || N < 1) return fail(MI_RAST_ERR_INVALID, "contrastive: need C, h, w, H, W, N >= 1 and S >= 0");
+    if (!rendered || !inv_norm || !norm_sum || !gates) return fail(MI_RAST_ERR_INVALID, "contrastive: null pointer");
+    if (S > 0 && (!ray_yx || !out || !ray_feat || !inv_len)) return fail(MI_RAST_ERR_INVALID, "contrastive: null ray buffers");
+    const size_t HW = (size_t)h * w;
+    const bool vec = HW % 4 == 0 && ((uintptr_t)rendered % 16) == 0 && ((uintptr_t)inv_norm % 16) == 0;
+    const size_t per_block = (size_t)CT_THREADS * (vec ? 4 : 1);
+    const uint32_t dense_blocks = (uint32_t)((HW + per_block - 1) / per_block);
+    const uint32_t ray_blocks = (uint32_t)((S + CT_THREADS / 64 - 1) / (CT_THREADS / 64));
+    if (vec)
+        hipLaunchKernelGGL(contrastive_fwd_kernel<4>, dim3(dense_blocks + ray_blocks), dim3(CT_THREADS), 0, stream, C, h, w, rendered, H, W, S,
+                           ray_yx, N, gates, out, ray_feat, inv_len, inv_norm, norm_sum, dense_blocks);
+    else
+        hipLaunchKernelGGL(contrastive_fwd_kernel<1>, dim3(dense_blocks + ray_blocks), dim3(CT_THREADS), 0, stream, C, h, w, rendered, H, W, S,
+                           ray_yx, N, gates, out, ray_feat, inv_len, inv_norm, norm_sum, dense_blocks);
+    HIP_TRY(hipGetLastError());
+    return MI_RAST_OK;
+}
+
+int mi_contrastive_backward(int C, int h, int w, const float* rendered, int H, int W, int S, const int* ray_yx, int N,
+                            const float* gates, const float* out, const float* ray_feat, const float* inv_len,
+                            const float* inv_norm, const float* dL_dout, const float* g_norm, float* dL_drendered,
+                            float* dL_dgates, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C < 1 || h < 1 || w < 1 || H < 1 || W < 1 || S < 0 || N < 1) return fail(MI_RAST_ERR_INVALID, "contrastive: need C, h, w, H, W, N >= 1 and S >= 0");
+    if (!rendered || !inv_norm || !dL_drendered) return fail(MI_RAST_ERR_INVALID, "contrastive: null pointer");
+    if (S > 0 && (!ray_yx || !out || !ray_feat || !inv_len || !dL_dout || !gates || !dL_dgates)) return fail(MI_RAST_ERR_INVALID, "contrastive: null ray buffers");
+    const size_t lds = (size_t)(CT_THREADS / 64) * N * C * sizeof(float);
+    if (S > 0 && lds > 64 * 1024) return fail(MI_RAST_ERR_INVALID, "contrastive: N * C too large for the gate-gradient reduction (4 N C floats of LDS)");
+    const size_t HW = (size_t)h * w;
+    const bool vec = HW % 4 == 0 && ((uintptr_t)rendered % 16) == 0 && ((uintptr_t)inv_norm % 16) == 0 && ((uintptr_t)dL_drendered % 16) == 0;
+    const size_t per_block = (size_t)CT_THREADS * (vec ? 4 : 1);
+    const uint32_t dense_blocks = (uint32_t)((HW + per_block - 1) / per_block);
+    if (vec)
+        hipLaunchKernelGGL(contrastive_bwd_dense_kernel<4>, dim3(dense_blocks), dim3(CT_THREADS), 0, stream, C, h, w, rendered, inv_norm, g_norm, dL_drendered);
+    else
+        hipLaunchKernelGGL(contrastive_bwd_dense_kernel<1>, dim3(dense_blocks), dim3(CT_THREADS), 0, stream, C, h, w, rendered, inv_norm, g_norm, dL_drendered);
+    if (S > 0) {
+        const uint32_t ray_blocks = (uint32_t)((S + CT_THREADS / 64 - 1) / (CT_THREADS / 64));
+        hipLaunchKernelGGL(contrastive_bwd_rays_kernel, dim3(ray_blocks), dim3(CT_THREADS), lds, stream, C, h, w, H, W, S, ray_yx, N, gates, out,
+                           ray_feat, inv_len, dL_dout, dL_drendered, dL_dgates);
     }
     HIP_TRY(hipGetLastError());
     return MI_RAST_OK;

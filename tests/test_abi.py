@@ -19,8 +19,8 @@ def lib():
 
 
 def test_header_symbols_exported(lib):
-    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("mi_rast.h", "mi_knn_smooth.h", "mi_knn.h"))
-    declared = set(re.findall(r"\b(mi_(?:rast|knn)_[a-z_0-9]+)\s*\(", hdr)) - {"mi_rast_resize_fn", "mi_rast_last_error"} | {"mi_rast_last_error"}
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("mi_rast.h", "mi_knn_smooth.h", "mi_knn.h", "mi_contrastive.h"))
+    declared = set(re.findall(r"\b(mi_(?:rast|knn|contrastive)_[a-z_0-9]+)\s*\(", hdr)) - {"mi_rast_resize_fn", "mi_rast_last_error"} | {"mi_rast_last_error"}
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
