@@ -124,10 +124,33 @@ def get_smoothed_point_features(features: torch.Tensor, nmap: NeighbourMap, K: i
     return smooth_point_features(features, nmap, cols, normalize_out)
 
 
+def fused_get_smoothed_point_features(self, K=16, dropout=0.5):
+    """What `install_dropin(fuse_smoothing=True)` binds to the reference's FeatureGaussianModel.get_smoothed_point_features
+    (scene/gaussian_model_ff.py:338-364): same signature and state (`self.feature_smooth_map = {"K", "m"}`, built with
+    pytorch3d.ops.knn_points = the HIP KNN drop-in), same `torch.randperm(K)[:int(K*dropout)]` draw from the CPU generator, the
+    normalise -> gather -> mean and its backward in the fused kernels instead of PyTorch's (P, k, C) gather and index_put."""
+    if K <= 1:
+        return self._point_features
+    assert dropout < 0 or int(K * dropout) >= 1
+    with torch.no_grad():
+        if self.feature_smooth_map is None or self.feature_smooth_map["K"] != K:
+            import pytorch3d.ops
+            xyz = self.get_xyz
+            nearest_k_idx = pytorch3d.ops.knn_points(xyz.unsqueeze(0), xyz.unsqueeze(0), K=K).idx.squeeze()
+            self.feature_smooth_map = {"K": K, "m": nearest_k_idx}
+        m = self.feature_smooth_map["m"]
+        cached = getattr(self, "_mi_neighbour_map", None)
+        if cached is None or cached[0] is not m:           # inverse lists: once per neighbour map, like the map itself
+            cached = (m, NeighbourMap(m))
+            self._mi_neighbour_map = cached
+    cols = torch.randperm(K)[: int(K * dropout)] if 0 < dropout < 1 else None
+    return smooth_point_features(self._point_features, cached[1], cols, normalize_out=False)
+
+
 def knn_points_bruteforce(xyz: torch.Tensor, K: int, chunk: int = 4096) -> torch.Tensor:
     """K nearest neighbours (self included, nearest first) by chunked exhaustive search: what
     pytorch3d.ops.knn_points(xyz[None], xyz[None], K=K).idx.squeeze() returns.  O(P^2): the CHECKER of the HIP search
-    (seganygaussians_amd/knn.py) in the tests; build_neighbour_map uses the HIP search."""
+    (seganygaussians_amd/knn.py) in the tests; NeighbourMap.from_points uses the HIP search."""
     P = xyz.size(0)
     out = torch.empty((P, K), dtype=torch.int64, device=xyz.device)
     for s in range(0, P, chunk):

@@ -96,3 +96,75 @@ def test_hip_zero_rows_and_drop_in():
     assert (kn[:, 0].cpu() == torch.arange(400)).all()
     with pytest.raises(RuntimeError):
         ks.NeighbourMap(torch.tensor(idx))  # CPU tensor: no CPU path
+
+
+def test_install_dropin_fuse_smoothing_patches_on_import(tmp_path, monkeypatch):
+    """install_dropin(fuse_smoothing=True) rebinds FeatureGaussianModel.get_smoothed_point_features right after the reference
+    module scene.gaussian_model_ff is imported (here: a stand-in package), and keeps the original reachable."""
+    import importlib
+    import sys
+
+    import seganygaussians_amd
+    from seganygaussians_amd import knn_smooth as ks
+    pkg = tmp_path / "scene"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "gaussian_model_ff.py").write_text(
+        "class FeatureGaussianModel:\n    def get_smoothed_point_features(self, K=16, dropout=0.5):\n        return 'reference'\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    for k in ("scene", "scene.gaussian_model_ff"):
+        monkeypatch.delitem(sys.modules, k, raising=False)
+    seganygaussians_amd.install_dropin(fuse_smoothing=True)
+    mod = importlib.import_module("scene.gaussian_model_ff")
+    cls = mod.FeatureGaussianModel
+    assert cls.get_smoothed_point_features is ks.fused_get_smoothed_point_features
+    assert cls._reference_get_smoothed_point_features(cls()) == "reference"
+    assert not any(isinstance(f, seganygaussians_amd._PatchOnImport) for f in sys.meta_path)
+    seganygaussians_amd.install_dropin(fuse_smoothing=True)     # already imported: patch is idempotent
+    assert cls.get_smoothed_point_features is ks.fused_get_smoothed_point_features
+    for k in ("scene", "scene.gaussian_model_ff"):
+        sys.modules.pop(k, None)
+
+
+@pytest.mark.gpu
+def test_hip_full_size_parity_and_time_vs_reference_expression():
+    """SURVEY 8(f) row 1 at the benchmarked size: 1 M Gaussians x 32-D, K = 16, 8 selected columns (dropout 0.5).  The fused
+    kernels against the reference's own PyTorch expression (scene/gaussian_model_ff.py:354-362) on the same device: values,
+    the gradient that reaches the features, and the time of forward + backward of both."""
+    from seganygaussians_amd import knn_smooth as ks
+    dev = torch.device("cuda:0")
+    P, C, K = 1_000_000, 32, 16
+    g = torch.Generator().manual_seed(3)
+    xyz = (torch.randn(P, 3, generator=g) * torch.tensor([3.0, 2.0, 1.0])).to(dev)
+    feats = (torch.randn(P, C, generator=g) * (0.1 + 3 * torch.rand(P, 1, generator=g))).to(dev)
+    up = torch.randn(P, C, generator=g).to(dev)
+    nmap = ks.NeighbourMap.from_points(xyz, K)
+    idx = nmap.idx.long()
+    assert torch.equal(idx[:, 0], torch.arange(P, device=dev))
+    cols = torch.randperm(K, generator=g)[:8]
+
+    def reference(f):
+        normed = torch.nn.functional.normalize(f, dim=-1, p=2)
+        return normed[idx[:, cols.to(dev)], :].mean(dim=1)
+
+    def timed(fn):
+        f = feats.clone().requires_grad_(True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(f)
+        out.backward(up)
+        e1.record()
+        torch.cuda.synchronize()
+        return out.detach(), f.grad, e0.elapsed_time(e1)
+
+    fused = lambda f: ks.smooth_point_features(f, nmap, cols, normalize_out=False)
+    timed(fused), timed(reference)
+    got, gg, ms = min((timed(fused) for _ in range(3)), key=lambda r: r[2])
+    want, gw, ms_ref = min((timed(reference) for _ in range(3)), key=lambda r: r[2])
+    print(f"KNN smoothing at {P} x {C}, K = {K} / 8 columns: fused fwd+bwd {ms:.3f} ms, reference expression {ms_ref:.3f} ms")
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-6 * float(want.abs().max()))
+    torch.testing.assert_close(gg, gw, rtol=0, atol=2e-5 * float(gw.abs().max()))
+    rel = float((gg - gw).norm() / gw.norm())
+    assert rel < 2e-6, rel
+    assert ms < ms_ref

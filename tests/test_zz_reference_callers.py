@@ -215,3 +215,54 @@ def test_render_contrastive_feature_and_smoothing(ref):
     d = torch.cdist(pc.get_xyz.double(), pc.get_xyz.double())
     want = d.topk(16, dim=1, largest=False).indices
     assert (nmap.sort(1).values == want.sort(1).values).all(1).float().mean() > 0.999
+
+
+def test_fused_smoothing_opt_in_on_the_reference_model(ref):
+    """install_dropin(fuse_smoothing=True) rebinds the reference's FeatureGaussianModel.get_smoothed_point_features to the fused
+    HIP kernels.  Same CPU-generator column draw, so: same returned features, same `_point_features.grad`, same render through
+    render_contrastive_feature(smooth_type='traditional') as the reference's own method (kept as _reference_get_...)."""
+    import sys
+    P, W, H = 8000, 256, 160
+    sc, focal = _scene(P, W, H, 32, seed=64)
+    pc = ref.FeatureGaussianModel(32)
+    _fill_geometry(pc, sc, ref)
+    pc._point_features = _param(sc.features * np.linspace(0.5, 2.0, P, dtype=np.float32)[:, None])
+    cam = _camera(ref, W, H, focal)
+    bg = torch.zeros(32, device=DEV)
+    cls = ref.FeatureGaussianModel
+    assert sys.modules["scene.gaussian_model_ff"].FeatureGaussianModel is cls
+    seganygaussians_amd.install_dropin(fuse_smoothing=True)
+    try:
+        assert cls._mi_fused_smoothing and cls.get_smoothed_point_features is not cls._reference_get_smoothed_point_features
+        up = torch.randn(P, 32, generator=torch.Generator().manual_seed(1)).to(DEV)
+        torch.manual_seed(11)
+        want = cls._reference_get_smoothed_point_features(pc, K=16, dropout=0.5)
+        want.backward(up)
+        gw = pc._point_features.grad.clone()
+        pc._point_features.grad = None
+        torch.manual_seed(11)
+        got = pc.get_smoothed_point_features(K=16, dropout=0.5)
+        got.backward(up)
+        gg = pc._point_features.grad.clone()
+        pc._point_features.grad = None
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-6 * float(want.abs().max()))
+        torch.testing.assert_close(gg, gw, rtol=0, atol=2e-5 * float(gw.abs().max()))
+        assert pc._mi_neighbour_map[0] is pc.feature_smooth_map["m"]
+        # all K columns (dropout outside (0, 1)), and K <= 1 returns the raw features
+        torch.testing.assert_close(pc.get_smoothed_point_features(K=16, dropout=-1),
+                                   cls._reference_get_smoothed_point_features(pc, K=16, dropout=-1), rtol=0, atol=2e-6)
+        assert pc.get_smoothed_point_features(K=1) is pc._point_features
+        # through the reference's renderer
+        torch.manual_seed(12)
+        out_f = ref.gr.render_contrastive_feature(cam, pc, PIPE, bg, norm_point_features=True, smooth_type="traditional", smooth_K=16)
+        cls.get_smoothed_point_features, fused = cls._reference_get_smoothed_point_features, cls.get_smoothed_point_features
+        try:
+            torch.manual_seed(12)
+            out_r = ref.gr.render_contrastive_feature(cam, pc, PIPE, bg, norm_point_features=True, smooth_type="traditional", smooth_K=16)
+        finally:
+            cls.get_smoothed_point_features = fused
+        hp.assert_close("render with fused smoothing", out_f["render"].detach().cpu().numpy(), out_r["render"].detach().cpu().numpy(),
+                        flip_frac=hp.FLIP_FRAC)
+    finally:
+        cls.get_smoothed_point_features = cls._reference_get_smoothed_point_features
+        cls._mi_fused_smoothing = False
