@@ -149,6 +149,14 @@ PYREF_MODULES = {
     "utils.general_utils": "utils/general_utils.py",
     "utils.graphics_utils": "utils/graphics_utils.py",
     "utils.system_utils": "utils/system_utils.py",
+    # the training / rendering scripts north_star names, with the scene loader they go through (tests/test_zz_reference_training.py)
+    "utils.camera_utils": "utils/camera_utils.py",
+    "scene.colmap_loader": "scene/colmap_loader.py",
+    "scene.dataset_readers": "scene/dataset_readers.py",
+    "scene": "scene/__init__.py",                              # Scene
+    "arguments": "arguments/__init__.py",                      # ModelParams / OptimizationParams / PipelineParams
+    "train_contrastive_feature": "train_contrastive_feature.py",
+    "render": "render.py",
 }
 PYREF_DIR = os.path.join(OUT_DIR, "pyref")
 

@@ -53,3 +53,38 @@ def test_ascii_ply(tmp_path):
     p = ply_io.read_vertex_ply(path)
     np.testing.assert_array_equal(p["z"], np.array([2, 5], np.float32))
     assert p["red"].dtype == np.uint8 and p["red"][1] == 7
+
+
+def test_ply_io_against_the_plyfile_calls_of_the_reference(tmp_path):
+    """The reference writes its PLY files with PlyElement.describe(elements, 'vertex') + PlyData([el]).write(path) on a
+    structured all-'f4' array (scene/gaussian_model_ff.py:586-592) and reads them back property by property.  Through the
+    plyfile stand-in (tests/plyfile_shim.py: the header and record layout plyfile itself emits) both directions agree with
+    ply_io byte for byte."""
+    from tests import plyfile_shim as pf
+    rng = np.random.default_rng(2)
+    P, C = 123, 32
+    names = ply_io.feature_attributes(C)
+    cols = rng.normal(size=(P, len(names))).astype(np.float32)
+    elements = np.empty(P, dtype=[(n, "f4") for n in names])
+    elements[:] = list(map(tuple, cols))                        # the reference's own packing idiom
+    a, b = str(tmp_path / "ref.ply"), str(tmp_path / "ours.ply")
+    pf.PlyData([pf.PlyElement.describe(elements, "vertex")]).write(a)
+    ply_io.write_vertex_ply(b, names, cols)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    got = ply_io.load_feature_ply(a, C)
+    np.testing.assert_array_equal(got["point_features"], cols[:, 6:6 + C])
+    back = pf.PlyData.read(b)
+    assert [p.name for p in back.elements[0].properties] == names and back["vertex"].count == P
+    for i, n in enumerate(names):
+        np.testing.assert_array_equal(np.asarray(back.elements[0][n]), cols[:, i])
+    # storePly's layout (scene/dataset_readers.py:143-160): float positions / normals + uchar colours
+    dtype = [("x", "f4"), ("y", "f4"), ("z", "f4"), ("nx", "f4"), ("ny", "f4"), ("nz", "f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")]
+    pts = np.empty(5, dtype=dtype)
+    pts[:] = [tuple(list(rng.normal(size=6)) + list(rng.integers(0, 255, 3))) for _ in range(5)]
+    c = str(tmp_path / "points3D.ply")
+    pf.PlyData([pf.PlyElement.describe(pts, "vertex")]).write(c)
+    head = open(c, "rb").read().split(b"end_header\n")[0].decode().splitlines()
+    assert head[-3:] == ["property uchar red", "property uchar green", "property uchar blue"]
+    p = ply_io.read_vertex_ply(c)
+    np.testing.assert_array_equal(p["red"], pts["red"])
+    np.testing.assert_array_equal(p["y"], pts["y"])
