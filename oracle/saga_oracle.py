@@ -201,7 +201,10 @@ class BackwardOut:
     dL_dmask: Optional[np.ndarray] = None
 
 
-def backward(inp: Inputs, fwd: ForwardOut, dL_dout_color, dL_dout_mask=None) -> BackwardOut:
+def backward(inp: Inputs, fwd: ForwardOut, dL_dout_color, dL_dout_mask=None, exact_pairs=False) -> BackwardOut:
+    """exact_pairs=False: binary64 sums of per-pair terms rounded to binary32 exactly like the reference's kernel (the parity
+    checker).  exact_pairs=True: the per-pair values in binary64 as well (decisions still binary32): the yardstick for
+    comparing two implementations' rounding noise -- it shares neither's (saga_rast_oracle.c: render_backward)."""
     L = lib()
     means3D = _f32(inp.means3D)
     P = 0 if means3D is None else means3D.reshape(-1, 3).shape[0]
@@ -229,7 +232,7 @@ def backward(inp: Inputs, fwd: ForwardOut, dL_dout_color, dL_dout_mask=None) -> 
                            float(inp.tanfovx), float(inp.tanfovy), _ptr(a["dpix"]), _ptr(a["dmask"]),
                            _ptr(a["mask"]), _ptr(o.dL_dmeans2D), _ptr(o.dL_dconic), _ptr(o.dL_dopacity),
                            _ptr(o.dL_dcolors), _ptr(o.dL_dmask), _ptr(o.dL_dmeans3D), _ptr(o.dL_dcov3D),
-                           _ptr(o.dL_dsh), _ptr(o.dL_dscales), _ptr(o.dL_drotations), 1)
+                           _ptr(o.dL_dsh), _ptr(o.dL_dscales), _ptr(o.dL_drotations), 2 if exact_pairs else 1)
     for k, v in list(o.__dict__.items()):
         if v is not None:
             setattr(o, k, v[:P] if k != "dL_dsh" else v[:P, :M])

@@ -637,10 +637,16 @@ static inline void atomic_add_d(double* p, double v)
 /* renderCUDA backward: CF/cuda_rasterizer/backward.cu:399-559; DEPTH variant
  * DEPTH/cuda_rasterizer/backward.cu:457,516 (dL_dmask); mask-only DEPTH/.../backward.cu:568-660.
  * Per-Gaussian sums go to binary64 arrays acc_* (size P each field). */
+/* exact_pairs: the per-pair VALUES (G, alpha, T, accum_rec, dL/dalpha, the six geometric terms) are evaluated in binary64 from
+ * the same binary32 inputs, while every DECISION (power > 0, alpha < 1/255, the contributor range) is taken by the binary32
+ * expressions above, exactly as the reference takes it.  The default mode rounds every per-pair value like the reference's
+ * kernel does and is therefore a yardstick that shares the reference's per-pair rounding; this mode shares nobody's, which
+ * is what a comparison of two implementations' noise needs (tests/test_zz_reference_pin.py: error statistics). */
 static void render_backward(const saga_oracle_state* st, int C, const float* bg, const float* colors,
                             const float* dL_dpixels, const float* dL_dout_mask, int mask_only,
                             double* acc_color /*P*C*/, double* acc_mean2D /*P*2*/,
-                            double* acc_conic /*P*3*/, double* acc_opacity /*P*/, double* acc_mask /*P*/)
+                            double* acc_conic /*P*3*/, double* acc_opacity /*P*/, double* acc_mask /*P*/,
+                            int exact_pairs)
 {
     const int W = st->W, H = st->H;
     const int ntiles = st->tiles_x * st->tiles_y;
@@ -652,6 +658,7 @@ static void render_backward(const saga_oracle_state* st, int C, const float* bg,
         double* local = NULL;
         size_t local_cap = 0;
         float accum_rec[256], last_color[256], dL_dpixel[256];
+        double accum_d[256], last_color_d[256];
 #pragma omp for schedule(dynamic, 1)
         for (int tile = 0; tile < ntiles; tile++) {
             const int tx = tile % st->tiles_x, ty = tile / st->tiles_x;
@@ -692,6 +699,56 @@ static void render_backward(const saga_oracle_state* st, int C, const float* bg,
                     }
                     const float dL_dout_mask_i = dL_dout_mask ? dL_dout_mask[pix_id] : 0;
                     float last_alpha = 0;
+                    if (exact_pairs && !mask_only) {
+                        double Td = (double)T_final, last_alpha_d = 0.0, bg_dot_d = 0.0;
+                        for (int ch = 0; ch < C; ch++) {
+                            accum_d[ch] = 0.0;
+                            last_color_d[ch] = 0.0;
+                            bg_dot_d += (double)bg[ch] * (double)dL_dpixel[ch];
+                        }
+                        for (int j = last_contributor - 1; j >= 0; j--) {
+                            const uint32_t id = st->point_list[r0 + j];
+                            const float* co = st->conic_opacity + 4 * (size_t)id;
+                            {   /* decisions: the binary32 expressions of backward.cu:478-492 */
+                                const float dx = st->means2D[2 * id] - pixfx;
+                                const float dy = st->means2D[2 * id + 1] - pixfy;
+                                const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                                if (power > 0.0f) continue;
+                                if (fminf(0.99f, co[3] * expf(power)) < 1.0f / 255.0f) continue;
+                            }
+                            const double dx = (double)st->means2D[2 * id] - (double)pixfx;
+                            const double dy = (double)st->means2D[2 * id + 1] - (double)pixfy;
+                            const double power = -0.5 * ((double)co[0] * dx * dx + (double)co[2] * dy * dy) - (double)co[1] * dx * dy;
+                            const double G = exp(power);
+                            const double alpha = fmin((double)0.99f, (double)co[3] * G);
+                            Td = Td / (1.0 - alpha);
+                            const double dchannel_dcolor = alpha * Td;
+                            double* loc = local + (size_t)j * NF;
+                            double dL_dalpha = 0.0;
+                            for (int ch = 0; ch < C; ch++) {
+                                const double c = (double)colors[(size_t)id * C + ch];
+                                accum_d[ch] = last_alpha_d * last_color_d[ch] + (1.0 - last_alpha_d) * accum_d[ch];
+                                last_color_d[ch] = c;
+                                dL_dalpha += (c - accum_d[ch]) * (double)dL_dpixel[ch];
+                                loc[ch] += dchannel_dcolor * (double)dL_dpixel[ch];
+                            }
+                            if (dL_dout_mask) loc[C + 6] += dchannel_dcolor * (double)dL_dout_mask_i;
+                            dL_dalpha *= Td;
+                            last_alpha_d = alpha;
+                            dL_dalpha += (-(double)T_final / (1.0 - alpha)) * bg_dot_d;
+                            const double dL_dG = (double)co[3] * dL_dalpha;
+                            const double gdx = G * dx, gdy = G * dy;
+                            const double dG_ddelx = -gdx * (double)co[0] - gdy * (double)co[1];
+                            const double dG_ddely = -gdy * (double)co[2] - gdx * (double)co[1];
+                            loc[C + 0] += dL_dG * dG_ddelx * (double)ddelx_dx;
+                            loc[C + 1] += dL_dG * dG_ddely * (double)ddely_dy;
+                            loc[C + 2] += -0.5 * gdx * dx * dL_dG;
+                            loc[C + 3] += -0.5 * gdx * dy * dL_dG;
+                            loc[C + 4] += -0.5 * gdy * dy * dL_dG;
+                            loc[C + 5] += G * dL_dalpha;
+                        }
+                        continue;
+                    }
                     /* back to front; entries with contributor >= last_contributor are skipped
                      * (backward.cu:485-487), so start at list position last_contributor-1 */
                     for (int j = last_contributor - 1; j >= 0; j--) {
@@ -999,7 +1056,7 @@ void saga_oracle_backward(const saga_oracle_state* st, int P, int D, int M, int 
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                           int accum_double)
 {
-    (void)mask; (void)accum_double;
+    (void)mask;   /* accum_double: 1 = binary64 sums of binary32 per-pair terms (default); 2 = binary64 per-pair values too */
     if (P == 0) return; /* CF/rasterize_points.cu:161 */
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
@@ -1011,7 +1068,7 @@ void saga_oracle_backward(const saga_oracle_state* st, int P, int D, int M, int 
     double* acc_opacity = (double*)calloc(p, sizeof(double));
     double* acc_mask = dL_dmask ? (double*)calloc(p, sizeof(double)) : NULL;
     render_backward(st, C, background, color_ptr, dL_dpix, dL_dmask ? dL_dout_mask : NULL, 0, acc_color,
-                    acc_mean2D, acc_conic, acc_opacity, acc_mask);
+                    acc_mean2D, acc_conic, acc_opacity, acc_mask, accum_double == 2);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) {
         for (int ch = 0; ch < C; ch++) dL_dcolor[(size_t)i * C + ch] += (float)acc_color[(size_t)i * C + ch];
@@ -1044,7 +1101,7 @@ void saga_oracle_mask_backward(const saga_oracle_state* st, int P, int W, int H,
     (void)W; (void)H; (void)accum_double;
     if (P == 0) return;
     double* acc_mask = (double*)calloc((size_t)P, sizeof(double));
-    render_backward(st, 0, NULL, NULL, NULL, dL_dout_mask, 1, NULL, NULL, NULL, NULL, acc_mask);
+    render_backward(st, 0, NULL, NULL, NULL, dL_dout_mask, 1, NULL, NULL, NULL, NULL, acc_mask, 0);
     for (int i = 0; i < P; i++) dL_dmask[i] += (float)acc_mask[i];
     free(acc_mask);
 }

@@ -28,6 +28,18 @@
 
 namespace mirast {
 
+// 1 / x to ~0.5 ulp: v_rcp_f32 (1 ulp) plus one Newton step (two FMAs).  T is divided by (1 - alpha) once per row and the
+// quotients are chained through the whole list: the reference uses a correctly rounded division there (backward.cu:487).
+#ifndef MI_BWD_RCP_REFINE
+#define MI_BWD_RCP_REFINE 1
+#endif
+__device__ __forceinline__ float rcp_refined(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    if (MI_BWD_RCP_REFINE) r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
+
 template <int C>
 struct BwvCfg {
     static constexpr int FROW = C + 4;           // padded feature row (floats): conflict-free 16-lane b128 operand reads
@@ -338,7 +350,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             const float tG = t0 >= (1.0f / 255.0f) ? t0 : 0.f;   // opacity * G of a contributing row
             const float alpha = fminf(0.99f, tG);
             const float om = 1.f - alpha;
-            const float inv = __builtin_amdgcn_rcpf(om);
+            const float inv = rcp_refined(om);
             T = T * inv;
             const float w = alpha * T;  // dchannel_dcolor
             const float dS = my_wa[rr * WROW + lane] - Rcur;
@@ -367,7 +379,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
                 om[k] = 1.f - al[k];
             }
             float Tk[4];
-            Tk[3] = T * __builtin_amdgcn_rcpf((om[0] * om[1]) * (om[2] * om[3]));
+            Tk[3] = T * rcp_refined((om[0] * om[1]) * (om[2] * om[3]));
             Tk[2] = Tk[3] * om[3];
             Tk[1] = Tk[2] * om[2];
             Tk[0] = Tk[1] * om[1];

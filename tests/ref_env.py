@@ -15,7 +15,7 @@ from oracle import build_ref
 MODULES = ("utils.system_utils", "utils.general_utils", "utils.graphics_utils", "utils.sh_utils", "scene.cameras",
            "scene.gaussian_model", "scene.gaussian_model_ff", "scene.colmap_loader", "scene.dataset_readers", "utils.camera_utils",
            "arguments", "scene", "gaussian_renderer", "train_contrastive_feature", "render")
-_TOUCHED = ("plyfile", "torchvision", "torchvision.utils", "utils", "scene", "arguments", "gaussian_renderer",
+_TOUCHED = ("plyfile", "torchvision", "torchvision.utils", "sklearn", "sklearn.preprocessing", "utils", "scene", "arguments", "gaussian_renderer",
             "train_contrastive_feature", "render")
 
 
@@ -39,6 +39,30 @@ def _save_image(tensor, path, **_):
     Image.fromarray(a).save(path)
 
 
+class _QuantileTransformer:
+    """sklearn.preprocessing.QuantileTransformer(output_distribution='uniform') as train_contrastive_feature.py:41-62 uses it
+    (fit on a column of mask scales, transform to [0, 1]) -- for boxes without scikit-learn (the GPU test image has none)."""
+
+    def __init__(self, output_distribution="uniform", n_quantiles=1000):
+        assert output_distribution == "uniform"
+        self.n_quantiles = n_quantiles
+
+    def fit(self, X):
+        import numpy as np
+        X = np.asarray(X, np.float64).reshape(-1)
+        n = min(self.n_quantiles, X.size)
+        self.references_ = np.linspace(0, 1, n)
+        self.quantiles_ = np.nanpercentile(X, self.references_ * 100)
+        return self
+
+    def transform(self, X):
+        import numpy as np
+        X = np.asarray(X, np.float64)
+        q, r = self.quantiles_, self.references_
+        out = 0.5 * (np.interp(X.reshape(-1), q, r) - np.interp(-X.reshape(-1), -q[::-1], -r[::-1]))
+        return out.reshape(X.shape)
+
+
 class ReferenceEnv:
     """Context manager: `with ReferenceEnv() as ref: ref.mod['train_contrastive_feature'].training(...)`."""
 
@@ -51,6 +75,13 @@ class ReferenceEnv:
         tv.utils = types.ModuleType("torchvision.utils")
         tv.utils.save_image = _save_image
         sys.modules["torchvision"], sys.modules["torchvision.utils"] = tv, tv.utils
+        try:
+            import sklearn.preprocessing  # noqa: F401
+        except ImportError:
+            sk = types.ModuleType("sklearn")
+            sk.preprocessing = types.ModuleType("sklearn.preprocessing")
+            sk.preprocessing.QuantileTransformer = _QuantileTransformer
+            sys.modules["sklearn"], sys.modules["sklearn.preprocessing"] = sk, sk.preprocessing
         for pkg in ("utils", "scene"):   # packages: `utils` has no __init__ in the reference, scene/__init__.py is executed last
             m = types.ModuleType(pkg)
             m.__path__ = []
