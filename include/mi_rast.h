@@ -15,7 +15,9 @@
  *    reference's "empty tensor -> nullptr" convention (CF/.../__init__.py:196-206).
  *  - fp32, contiguous; out_color / dL_dpix are CHW; colors_precomp is (P,C); shs is (P,M,3).
  *  - `channels` is the reference's compile-time NUM_CHANNELS (config.h:15 = 3,
- *    config_contrastive_f.h:15 = 32); supported: 3, 32, 64 (mi_rast_supported_channels()).
+ *    config_contrastive_f.h:15 = 32), a RUN-TIME argument here; supported: 3 and every multiple of 16 up to 256
+ *    (mi_rast_supported_channels()).  32 and 64 run in one pass of the blend kernels, other widths in channel blocks of
+ *    64 / 32 / 16, one pass each (e.g. 112 = 64 + 32 + 16); anything else returns MI_RAST_ERR_INVALID.
  *  - `mask != NULL` selects the DEPTH variant (adds out_mask/out_depth, dL_dmask).
  *  - `stream` is a hipStream_t (0 = null stream).  The rendering entry points are RE-ENTRANT: they keep no
  *    state between calls (every mode is a per-call argument: `flags`, `features_ready_event`), all memory is

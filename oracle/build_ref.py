@@ -15,6 +15,7 @@ compared with the reference directly, at sizes the CPU oracle would take too lon
 Variants (one .so each; the reference fixes NUM_CHANNELS at compile time, CF/cuda_rasterizer/config_contrastive_f.h):
     cf32    CF/    NUM_CHANNELS 32   diff_gaussian_rasterization_contrastive_f  (the headline path)
     cf64    CF/    NUM_CHANNELS 64   what a user builds for 64-D features (cfg5)
+    cf16 / cf128  CF/  NUM_CHANNELS 16 / 128   (parity of the product's channel blocks: any multiple of 16)
     base3   BASE/  NUM_CHANNELS 3    diff_gaussian_rasterization
     depth3  DEPTH/ NUM_CHANNELS 3    diff_gaussian_rasterization_depth (mask + depth + mask-only pair)
     knn     simple-knn/simple_knn.cu  (distCUDA2's core, SimpleKNN::knn)
@@ -48,6 +49,8 @@ VARIANTS = {
     "cf32": ("cf", 32, [], "off"),
     "cf32_fast": ("cf", 32, [], "fast"),
     "cf64": ("cf", 64, [], "off"),
+    "cf16": ("cf", 16, [], "off"),      # the narrowest / widest feature the product's channel blocks cover in the parity tests
+    "cf128": ("cf", 128, [], "off"),
     "base3": ("base", 3, ["-DREF_BASE"], "off"),
     "depth3": ("depth", 3, ["-DREF_DEPTH"], "off"),
 }

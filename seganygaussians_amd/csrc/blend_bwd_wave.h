@@ -50,7 +50,8 @@ struct BwvCfg {
 
 // C: channels as the MFMA tiling sees them (16, 32, 64); CR: channels in memory (CR == C, or 3 for RGB padded to C = 16).
 // WPB: waves (quadrants) per workgroup, 1 or 4 -- the waves of a workgroup never synchronise either way.
-template <int C, int CR = C, bool MASKGRAD = false, int WPB = 1, bool XEXP = false>
+// STRIDED: rows of `colors` / `dL_dcolors` are `cstride_arg` floats apart (one channel block of a wider feature); otherwise CR.
+template <int C, int CR = C, bool MASKGRAD = false, int WPB = 1, bool XEXP = false, bool STRIDED = false>
 __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ bg_color,
@@ -58,9 +59,12 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dout_mask,
     float* __restrict__ gpack /*[P,8] packed field gradients*/, float* __restrict__ dL_dcolors,
     uint32_t* __restrict__ queue_ctr /* eight zeroed work-queue counters (common.h: xcd_grab) */,
+    int cstride_arg /* STRIDED: floats between the rows of two Gaussians in `colors` and `dL_dcolors` = the full channel count of
+                       the feature this launch handles one channel block of (both pointers then point at the block) */,
     int ablate /* timing experiments: profiling build only (common.h: MI_ABLATE) */)
 {
     constexpr int FROW = BwvCfg<C>::FROW, QCAP = BwvCfg<C>::QCAP, FEAT4 = BwvCfg<C>::FEAT4;
+    const int cstride = STRIDED ? cstride_arg : CR;   // (a compile-time constant in the common case: no 64-bit multiply, no extra registers)
     constexpr int CPL = C / 4;   // channels per lane in the S contraction: lane (n16, kq) holds channels CPL*kq .. +CPL-1
     constexpr int NB = C / 16;   // 16-channel blocks of the dF contraction
     constexpr int F4 = C / 4;    // float4s per feature row
@@ -245,9 +249,9 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             const int g = min(e / F4, n - 1), part = e % F4;
             const size_t gid = (size_t)s_queue[(qh + g) & (QCAP - 1)].y;
             if constexpr (CR == C) {
-                featpf[k] = reinterpret_cast<const float4*>(colors + gid * C)[part];
+                featpf[k] = reinterpret_cast<const float4*>(colors + gid * (size_t)cstride)[part];
             } else {  // RGB: three floats per Gaussian (part 0); the other 13 operand channels are zero
-                featpf[k] = make_float4(colors[gid * 3 + 0], colors[gid * 3 + 1], colors[gid * 3 + 2], 0.f);
+                featpf[k] = make_float4(colors[gid * (size_t)cstride + 0], colors[gid * (size_t)cstride + 1], colors[gid * (size_t)cstride + 2], 0.f);
             }
         }
     };
@@ -464,11 +468,11 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
 #ifdef MI_RAST_PROFILING
                 if (MI_ABLATE(16384) && !lowest_q) continue;
 #endif
-                if (MI_ABLATE(512)) { dL_dcolors[(size_t)gid * CR + ch] = facc[nb][r]; continue; }  // plain stores instead of atomics (wrong results)
+                if (MI_ABLATE(512)) { dL_dcolors[(size_t)gid * cstride + ch] = facc[nb][r]; continue; }  // plain stores instead of atomics (wrong results)
                 if constexpr (CR == C) {
-                    atomicAdd(&dL_dcolors[(size_t)gid * CR + ch], facc[nb][r]);
+                    atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], facc[nb][r]);
                 } else {
-                    if (ch < CR) atomicAdd(&dL_dcolors[(size_t)gid * CR + ch], facc[nb][r]);
+                    if (ch < CR) atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], facc[nb][r]);
                     else if (MASKGRAD && ch == CR) atomicAdd(&gpack[(size_t)gid * 8 + 6], facc[nb][r]);
                 }
             }

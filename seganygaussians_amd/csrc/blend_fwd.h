@@ -44,6 +44,8 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed,
     uint32_t* __restrict__ tile_nsurv, const float* __restrict__ bg_color, float* __restrict__ out_color,
     float* __restrict__ out_mask, float* __restrict__ out_depth,
+    int cstride /* floats between the feature rows of two Gaussians: C, or the full channel count when this launch renders one
+                   channel block of a wider feature (mi_rast.hip: channel blocks; `features` then points at the block) */,
     int ablate /* timing experiments only (MI_RAST_ABLATE_FWD); 0 in production */)
 {
     constexpr int CE = C + EXTRA;            // accumulated values per pixel
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
             s_pm[tid] = cur.pm;
             if constexpr (!VEC_STAGE) {
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) s_feat[tid * ROW + ch] = features[(size_t)cur.id * C + ch];
+                for (int ch = 0; ch < C; ch++) s_feat[tid * ROW + ch] = features[(size_t)cur.id * cstride + ch];
                 if constexpr (EXTRA >= 1) s_feat[tid * ROW + C] = mask[cur.id];
                 if constexpr (EXTRA >= 2) s_feat[tid * ROW + C + 1] = depths[cur.id];
             }
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fw
                 for (int k = 0; k < NK; k++) {
                     const int q = tid + BATCH * k;
                     const int g = q / F4, part = q % F4;
-                    v[k] = reinterpret_cast<const float4*>(features + (size_t)s_id[g < nb ? g : 0] * C)[part];
+                    v[k] = reinterpret_cast<const float4*>(features + (size_t)s_id[g < nb ? g : 0] * cstride)[part];
                 }
                 // pins every loaded value in registers here: hipcc otherwise sinks each load into the guarded store below
                 #pragma unroll

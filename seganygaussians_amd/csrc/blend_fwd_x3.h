@@ -50,13 +50,14 @@ __device__ __forceinline__ void split3_bf16x2(float a, float b, uint32_t& hi, ui
 }
 
 // C = 64: two 32-channel accumulator pairs (64 VGPRs), 24 MFMA per group, rows of 384 bytes: 2 workgroups per CU.
-template <int C, bool XEXP = false>
+template <int C, bool XEXP = false, bool STRIDED = false>
 __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
     int W, int H, const float* __restrict__ features, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_consumed, uint32_t* __restrict__ tile_nsurv, const float* __restrict__ bg_color,
-    float* __restrict__ out_color)
+    float* __restrict__ out_color, int cstride_arg /* STRIDED: floats between feature rows (blend_fwd.h) */)
 {
+    const int cstride = STRIDED ? cstride_arg : C;
     static_assert(C == 32 || C == 64, "32-channel accumulator blocks");
     constexpr int F4 = C / 4, NCB = C / 32, XROW = 6 * C, PLANE = 2 * C;  // float4s per row; channel blocks; row / plane bytes
     __shared__ XRec s_rec[XB + 1];   // [XB] = padding record (opacity 0: never blends)
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
             for (int k = 0; k < NK; k++) {
                 const int q = tid + BATCH * k;
                 const int g = q / F4, part = q % F4;
-                v[k] = reinterpret_cast<const float4*>(features + (size_t)s_id[g < nb ? g : 0] * C)[part];
+                v[k] = reinterpret_cast<const float4*>(features + (size_t)s_id[g < nb ? g : 0] * cstride)[part];
             }
             // pins every loaded value in registers here: hipcc otherwise sinks each load into the guarded store below
 #pragma unroll

@@ -314,7 +314,15 @@ constexpr int ablate_env(const char*) { return 0; }
 std::atomic<bool> g_attr_set[MAX_DEVICES];
 std::mutex g_attr_mutex;
 
-bool channels_supported(int c) { return c == 3 || c == 32 || c == 64; }
+// RGB (+ the DEPTH variant's mask / depth planes), or any multiple of 16 feature channels up to 256: wider features are blended
+// in channel blocks of 64 / 32 / 16 (every pass re-evaluates alpha and T; the contraction over channels is linear, so the
+// backward's per-block geometry gradients add up in the packed record).  The reference compiles ONE NUM_CHANNELS into its
+// kernels (CF/cuda_rasterizer/config_contrastive_f.h:15).
+constexpr int MAX_CHANNELS = 256;
+constexpr int MAX_CHANNEL_BLOCKS = MAX_CHANNELS / 16;
+bool channels_supported(int c) { return c == 3 || (c >= 16 && c <= MAX_CHANNELS && c % 16 == 0); }
+// next block of a feature with `rem` channels left
+int channel_block(int rem) { return rem >= 64 ? 64 : (rem >= 32 ? 32 : 16); }
 
 // Stages shared by forward and mask_forward: CF/cuda_rasterizer/rasterizer_impl.cu:246-317.
 int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_rast_resize_fn binning_buffer,
@@ -526,31 +534,35 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
 template <int C, int EXTRA>
 void launch_blend_fwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin,
                       const GeomPtrs& geom, const float* features, const float* mask, const float* bg,
-                      float* out_color, float* out_mask, float* out_depth, bool xexp)
+                      float* out_color, float* out_mask, float* out_depth, bool xexp, int cstride = C)
 {
     const int g_ablate_fwd = ablate_env("MI_RAST_ABLATE_FWD");
     if (xexp)
         hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA, true>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
                            bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
-                           img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, g_ablate_fwd);
+                           img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, cstride, g_ablate_fwd);
     else
         hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA, false>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
                            bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
-                           img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, g_ablate_fwd);
+                           img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, cstride, g_ablate_fwd);
 }
 
 template <int C>
 void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const float* features,
-                         const float* bg, float* out_color, bool xexp)
+                         const float* bg, float* out_color, bool xexp, int cstride)
 {
-    if (xexp)
-        hipLaunchKernelGGL((blend_fwd_x3_kernel<C, true>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
-                           img.blend_count, vp.W, vp.H, features, img.final_T, img.n_contrib, img.tile_consumed, img.tile_nsurv, bg,
-                           out_color);
-    else
-        hipLaunchKernelGGL((blend_fwd_x3_kernel<C, false>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,
-                           img.blend_count, vp.W, vp.H, features, img.final_T, img.n_contrib, img.tile_consumed, img.tile_nsurv, bg,
-                           out_color);
+#define X3_LAUNCH(XE, ST)                                                                                                           \
+    hipLaunchKernelGGL((blend_fwd_x3_kernel<C, XE, ST>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,  \
+                       img.blend_count, vp.W, vp.H, features, img.final_T, img.n_contrib, img.tile_consumed, img.tile_nsurv, bg,        \
+                       out_color, cstride)
+    if (cstride == C) {
+        if (xexp) X3_LAUNCH(true, false);
+        else X3_LAUNCH(false, false);
+    } else {
+        if (xexp) X3_LAUNCH(true, true);
+        else X3_LAUNCH(false, true);
+    }
+#undef X3_LAUNCH
 }
 
 template <int C, bool MASKGRAD>
@@ -617,9 +629,12 @@ const char* mi_rast_version(void) { return "mi_rast 0.2 (gfx950)"; }
 
 int mi_rast_supported_channels(int* out, int n)
 {
-    const int all[3] = {3, 32, 64};
-    for (int i = 0; i < 3 && i < n; i++) out[i] = all[i];
-    return 3;
+    int k = 0;
+    if (k < n) out[k] = 3;
+    k++;
+    for (int c = 16; c <= MAX_CHANNELS; c += 16, k++)
+        if (k < n) out[k] = c;
+    return k;
 }
 
 // ---- fused KNN feature smoothing (mi_knn_smooth.h, knn_smooth.h) ------------------------------------------
@@ -816,7 +831,7 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_INDEX_REC] = c.take(p * sizeof(BlendRec));
     off[MI_GEOM_SORTED_IDX] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_SORT_TEMP] = c.take(depth_sort_temp_bytes(P) + 16);
-    off[MI_GEOM_BWD_PACK] = c.take(p * 8 * sizeof(float) + 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t));  // + the backward's work-queue counters
+    off[MI_GEOM_BWD_PACK] = c.take(p * 8 * sizeof(float) + MAX_CHANNEL_BLOCKS * 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t));  // + the backward's work-queue counters, one set per channel block
     off[MI_GEOM_RANK_REC] = c.take(p * sizeof(BlendRec));
     return c.off;
 }
@@ -884,7 +899,7 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
     hipStream_t stream = (hipStream_t)stream_;
     if (num_rendered) *num_rendered = 0;
     if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
-    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
+    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3 and the multiples of 16 up to 256)");
     if (mask && channels != 3) return fail(MI_RAST_ERR_INVALID, "mask/depth variant is built for 3 channels");
     // CF/cuda_rasterizer/rasterizer_impl.cu:242-245
     if (channels != 3 && colors_precomp == nullptr)
@@ -913,11 +928,27 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
         const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;
         if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
         else if (channels == 3) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
-        else if (flags & MI_RAST_F32_BLEND) {  // f32 FMA-chain forward (include/mi_rast.h)
-            if (channels == 32) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
-            else launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
-        } else if (channels == 32) launch_blend_fwd_x3<32>(vp, stream, img, bin, feature_ptr, background, out_color, xexp);
-        else launch_blend_fwd_x3<64>(vp, stream, img, bin, feature_ptr, background, out_color, xexp);
+        else {
+            // feature channels in blocks of 64 / 32 / 16 (one launch per block; see channels_supported)
+            const size_t HW = (size_t)width * height;
+            const bool f32_blend = (flags & MI_RAST_F32_BLEND) != 0;   // f32 FMA-chain forward (include/mi_rast.h)
+            for (int c0 = 0; c0 < channels;) {
+                const int cb = channel_block(channels - c0);
+                const float* f = feature_ptr + c0;
+                const float* bgp = background + c0;
+                float* out = out_color + (size_t)c0 * HW;
+                if (cb == 64) {
+                    if (f32_blend) launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
+                    else launch_blend_fwd_x3<64>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                } else if (cb == 32) {
+                    if (f32_blend) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
+                    else launch_blend_fwd_x3<32>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                } else {
+                    launch_blend_fwd<16, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
+                }
+                c0 += cb;
+            }
+        }
     }
     STAGE_CHECK("render");
     return MI_RAST_OK;
@@ -937,7 +968,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;
     const int g_ablate = ablate_env("MI_RAST_ABLATE");
     (void)g_ablate;
-    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3, 32, 64)");
+    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3 and the multiples of 16 up to 256)");
     const bool maskgrad = dL_dmask != nullptr;
     if (maskgrad && (channels != 3 || !dL_dout_mask)) return fail(MI_RAST_ERR_INVALID, "mask gradient needs 3 channels and dL_dout_mask");
 
@@ -949,31 +980,42 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     const float* color_ptr = (colors_precomp != nullptr) ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:389
     {
         StageTimer t(stream, MI_STAGE_BLEND_BWD);
-        HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float) + 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t), stream));
-        uint32_t* queue_ctr = reinterpret_cast<uint32_t*>(geom.bwd_pack + (size_t)P * 8);
+        HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float) + MAX_CHANNEL_BLOCKS * 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t), stream));
+        uint32_t* queue_ctr = reinterpret_cast<uint32_t*>(geom.bwd_pack + (size_t)P * 8);   // one set of eight counters per channel block
+        const float* bg_blk = background;
+        const float* colors_blk = color_ptr;
+        const float* dpix_blk = dL_dpix;
+        float* dcolor_blk = dL_dcolor;
+        int cstride = channels;
 #define LAUNCH_BWD_MFMA(...)                                                                                              \
     hipLaunchKernelGGL((blend_bwd_mfma_kernel<__VA_ARGS__>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,    \
                        bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib, dL_dpix, \
                        dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
         const uint32_t nt_ = vp.grid_x * vp.grid_y;
-#define LAUNCH_BWD_WAVE_(WPB, XE, ...)                                                                                    \
-    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE>), dim3(WPB == 1 ? 32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_) : nt_), dim3(64 * WPB), 0,    \
-                       stream, img.ranges, bin.blend_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, background, color_ptr, \
-                       img.final_T, img.n_contrib, dL_dpix, dL_dout_mask, geom.bwd_pack, dL_dcolor, queue_ctr, g_ablate)
+#define LAUNCH_BWD_WAVE_(WPB, XE, ST, ...)                                                                                    \
+    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE, ST>), dim3(WPB == 1 ? 32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_) : nt_), dim3(64 * WPB), 0,    \
+                       stream, img.ranges, bin.blend_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
+                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, g_ablate)
 #ifdef MI_RAST_PROFILING
-#define LAUNCH_BWD_WAVE(...)                                                    \
-    do {                                                                        \
-        if (xexp) LAUNCH_BWD_WAVE_(1, true, __VA_ARGS__);                       \
-        else if (g_ablate & 4096) LAUNCH_BWD_WAVE_(4, false, __VA_ARGS__);      \
-        else LAUNCH_BWD_WAVE_(1, false, __VA_ARGS__);                           \
+#define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
+    do {                                                                            \
+        if (xexp) LAUNCH_BWD_WAVE_(1, true, ST, __VA_ARGS__);                       \
+        else if (g_ablate & 4096) LAUNCH_BWD_WAVE_(4, false, ST, __VA_ARGS__);      \
+        else LAUNCH_BWD_WAVE_(1, false, ST, __VA_ARGS__);                           \
     } while (0)
 #else
-#define LAUNCH_BWD_WAVE(...)                                                    \
-    do {                                                                        \
-        if (xexp) LAUNCH_BWD_WAVE_(1, true, __VA_ARGS__);                       \
-        else LAUNCH_BWD_WAVE_(1, false, __VA_ARGS__);                           \
+#define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
+    do {                                                                            \
+        if (xexp) LAUNCH_BWD_WAVE_(1, true, ST, __VA_ARGS__);                       \
+        else LAUNCH_BWD_WAVE_(1, false, ST, __VA_ARGS__);                           \
     } while (0)
 #endif
+// (the row stride is a compile-time constant unless the launch handles one channel block of a wider feature)
+#define LAUNCH_BWD_WAVE(C_, CR_, MG_)                                               \
+    do {                                                                            \
+        if (cstride == CR_) LAUNCH_BWD_WAVE_ST(false, C_, CR_, MG_);                \
+        else LAUNCH_BWD_WAVE_ST(true, C_, CR_, MG_);                                \
+    } while (0)
 #ifdef MI_RAST_PROFILING
         if (g_ablate & 2048) {  // the tile-batched MFMA kernel (blend_bwd_mfma.h), for comparisons
             if (maskgrad) LAUNCH_BWD_MFMA(16, 3, true);
@@ -989,9 +1031,25 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
 #endif
         if (maskgrad) LAUNCH_BWD_WAVE(16, 3, true);
         else if (channels == 3) LAUNCH_BWD_WAVE(16, 3, false);
-        else if (channels == 32) LAUNCH_BWD_WAVE(32, 32, false);
-        else LAUNCH_BWD_WAVE(64, 64, false);
+        else {
+            // one launch per channel block: the feature gradient of the block, and the block's share of the geometry gradients
+            // (dL/dalpha is a sum over channels), which the launches accumulate in the packed record
+            const size_t HW = (size_t)width * height;
+            for (int c0 = 0; c0 < channels;) {
+                const int cb = channel_block(channels - c0);
+                bg_blk = background + c0;
+                colors_blk = color_ptr + c0;
+                dpix_blk = dL_dpix + (size_t)c0 * HW;
+                dcolor_blk = dL_dcolor + c0;
+                if (cb == 64) LAUNCH_BWD_WAVE(64, 64, false);
+                else if (cb == 32) LAUNCH_BWD_WAVE(32, 32, false);
+                else LAUNCH_BWD_WAVE(16, 16, false);
+                queue_ctr += 8 * XCD_QUEUE_STRIDE;
+                c0 += cb;
+            }
+        }
 #undef LAUNCH_BWD_WAVE
+#undef LAUNCH_BWD_WAVE_ST
 #undef LAUNCH_BWD_WAVE_
 #undef LAUNCH_BWD_MFMA
     }

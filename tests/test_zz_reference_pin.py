@@ -67,7 +67,7 @@ def _product_vs_ref(inp, variant=None, lean=True, fast_exp=None):
 
 
 def test_reference_libraries_present():
-    for v in ("cf32", "cf32_fast", "cf64", "base3", "depth3", "knn"):
+    for v in ("cf32", "cf32_fast", "cf64", "cf16", "cf128", "base3", "depth3", "knn"):
         assert sr.available(v), f"oracle/_ref/libsaga_ref_{v}.so missing: run python oracle/build_ref.py in the build container"
     assert sr.lib("cf32").saga_ref_channels() == 32 and sr.lib("cf64").saga_ref_channels() == 64
     assert sr.lib("base3").saga_ref_channels() == 3 and sr.lib("depth3").saga_ref_is_depth() == 1
@@ -102,6 +102,13 @@ def test_pin_features32_odd_size_random_bg():
 
 def test_pin_features64():
     _pin_oracle(hp.make_inputs(20_000, 320, 208, 64, seed=5, log_scale=math.log(0.04)))
+
+
+@pytest.mark.parametrize("C", [16, 128])
+def test_pin_features16_and_128(C):
+    """The reference compiles one NUM_CHANNELS into its kernels (CF/cuda_rasterizer/config_contrastive_f.h:15); builds with 16
+    and 128 pin the oracle at the ends of the range the product covers with channel blocks."""
+    _pin_oracle(hp.make_inputs(12_000, 320, 208, C, seed=30 + C, log_scale=math.log(0.04), bg="random"))
 
 
 def test_pin_depth_variant_with_mask():
@@ -182,6 +189,14 @@ def test_product_vs_ref_reduced_cfg3_cfg2_cfg5():
     _product_vs_ref(hp.inputs_from_config("cfg3", P=100_000))
     _product_vs_ref(hp.make_inputs(20_000, 480, 272, 3, seed=6, with_shs=True, sh_degree=3, use_mask=True, bg="random"))
     _product_vs_ref(hp.make_inputs(20_000, 320, 208, 64, seed=5, log_scale=math.log(0.04)))
+
+
+@pytest.mark.parametrize("C", [16, 128])
+def test_product_vs_ref_channel_blocks(C):
+    """Feature widths other than 32 / 64: the product blends them in channel blocks of 64 / 32 / 16 (mi_rast.hip:
+    channels_supported) -- against reference builds with NUM_CHANNELS = 16 and 128, fwd + bwd, lean == full."""
+    _product_vs_ref(hp.make_inputs(12_000, 320, 208, C, seed=30 + C, log_scale=math.log(0.04), bg="random"))
+    _product_vs_ref(hp.make_inputs(4_000, 203, 117, C, seed=40 + C, camera="orbit"))
 
 
 def _check_stats(stats, ref_stats, what, row_floor=1e-3, norm_floor=1e-4):
