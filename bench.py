@@ -23,9 +23,13 @@ Prints ONE JSON line (rank 0).  Extra objects:
                `stages` lists EVERY stage the same way; a stage whose frac exceeds 1 is flagged
                "algorithm replaced" (the reference's byte count for a pass this pipeline does not perform:
                never read it as bandwidth).  `whole_view.frac` uses the SURVEY byte count, `whole_view.frac_traffic`
-               the HBM bytes the counters saw (profiles/traffic.json).  `alu` = matrix / vector pipe busy fractions of the
-               dominant kernel from the committed PMC pass (profiles/alu.json): the blend kernels are issue-bound, not HBM-bound.
-  cpu_baseline the CPU oracle (kind "port") on this box's host cores, one full view (rank 0, N == 1).
+               the HBM bytes the counters saw, `whole_view.frac_without_replaced_stages` leaves the replaced stages' bytes out.
+               `traffic` / `alu` (matrix / vector pipe busy fractions of the dominant kernel) come from the committed PMC passes
+               (profiles/traffic_<cfg>.json, alu_<cfg>.json) and are null unless those were taken with the library being timed
+               (stamp = mi_rast_version(): a hash of sources, headers and flags).
+  cpu_baseline the CPU oracle (kind "port", gcc -O3 -march=native on this box) on this box's host cores, --cpu-views (3) full
+               views (rank 0, N == 1).
+  timing       median / p10 / p90 of ms per step over untimed blocks of ten steps after the timed region.
   parity       that same oracle run compared with the GPU outputs of the benchmarked configuration (product default
                lists): image and gradients, max-norm criterion of the tests + norm-wise error.
 """
@@ -97,6 +101,9 @@ def main():
     ap.add_argument("--settle", type=float, default=3.0,
                     help="minimum seconds of untimed settling blocks before the W warm-up steps (0 under a profiler: the "
                          "trace would hold thousands of views)")
+    ap.add_argument("--dist-blocks", type=int, default=20,
+                    help="untimed blocks of ten steps after the timed region for the median / p10 / p90 of ms per step (0: skip)")
+    ap.add_argument("--cpu-views", type=int, default=3, help="views the CPU baseline is timed over (SURVEY.md 8(d): >= 3)")
     ap.add_argument("--fast-exp", action="store_true",
                     help="run the product in its MI_RAST_FAST_EXP mode (v_exp_f32 instead of expf; noted in "
                          "config.arithmetic -- the headline number is the default mode)")
@@ -247,6 +254,27 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
+    # distribution (median + p10 / p90), reporting only and AFTER the timed region: blocks of ten steps, one
+    # synchronisation per block, max over ranks per block
+    dist_blocks = []
+    for _ in range(max(0, args.dist_blocks)):
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(10):
+            step()
+        barrier()
+        dtb = time.perf_counter() - tb
+        if dist is not None:
+            tt = torch.tensor([dtb], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtb = float(tt.item())
+        dist_blocks.append(1e2 * dtb)
+    timing = None
+    if dist_blocks:
+        q = np.percentile(np.asarray(dist_blocks), [10, 50, 90])
+        timing = {"blocks": len(dist_blocks), "steps_per_block": 10, "ms_per_step_p10": round(float(q[0]), 4),
+                  "ms_per_step_median": round(float(q[1]), 4), "ms_per_step_p90": round(float(q[2]), 4),
+                  "note": "untimed blocks after the K timed steps; `value` and `ms_per_step` are the mean over exactly K steps"}
     if rank == 0:
         print(f"[bench] {len(block_ms)} settling blocks of {nb} steps, ms/step: first {block_ms[:8]} min {min(block_ms)} "
               f"last {block_ms[-5:]}; timed region {ms_per_step:.3f} ms/step", file=sys.stderr)
@@ -314,17 +342,25 @@ def main():
         ab = algorithmic_bytes(counters, C, forward_only=fwd_only, sh_coeffs=16 if fwd_only else 0, extra=2 if fwd_only else 0)
         dom = max((k for k in stages_ms), key=lambda k: stages_ms[k])
         achieved = ab[dom] / (stages_ms[dom] * 1e-3) / 1e9 if stages_ms[dom] > 0 else 0.0
-        # HBM bytes the PMC passes saw (tools/collect_profiles.sh -> profiles/traffic.json); measured on cfg3
-        traffic_all, alu = {}, None
-        if args.config == "cfg3":
+        # HBM bytes / pipe-busy fractions the PMC passes saw (tools/collect_profiles.sh -> profiles/traffic_<cfg>.json, alu_<cfg>.json).
+        # They are measurements of ONE build: each file carries the stamp of the library it was taken with
+        # (mi_rast_version(): a hash of the sources, headers and flags), and a file whose stamp is not the loaded library's is
+        # ignored -- the line then says null, never a number from another build.
+        lib_version = _lib.load().mi_rast_version().decode()
+        traffic_all, alu, pmc_note = {}, None, None
+
+        def stamped(name):
             try:
-                traffic_all = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                d = json.load(open(os.path.join(ROOT, "profiles", f"{name}_{args.config}.json")))
             except Exception:  # noqa: BLE001
-                traffic_all = {}
-            try:
-                alu = json.load(open(os.path.join(ROOT, "profiles", "alu.json"))).get(dom)
-            except Exception:  # noqa: BLE001
-                alu = None
+                return None, "no PMC summary for this configuration"
+            if d.get("_stamp") != lib_version:
+                return None, f"PMC summary is of another build ({d.get('_stamp')}): ignored"
+            return d, d.get("_source")
+        traffic_all, pmc_note = stamped("traffic")
+        traffic_all = traffic_all or {}
+        alu_all, _ = stamped("alu")
+        alu = (alu_all or {}).get(dom)
         tr = lambda k: (traffic_all.get(k) or {}).get("bytes_per_launch")
         stage_rows = {}
         for k, ms_k in stages_ms.items():
@@ -339,25 +375,31 @@ def main():
             stage_rows[k] = row
         total_traffic = sum(tr(k) for k in stages_ms if tr(k)) if traffic_all else None
         wv_ach = ab["total"] / (ms_per_step * 1e-3) / 1e9
+        # the same without the stages whose byte count is the reference's pass that this pipeline replaces (frac > 1 above)
+        kept = sum(a for k, a in ab.items() if k != "total" and not (k in stage_rows and stage_rows[k]["frac"] > 1.0))
+        wv_kept = kept / (ms_per_step * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": tr(dom),
                     "algorithmic_bytes": ab[dom], "kernel_ms": round(stages_ms[dom], 4),
-                    "alu": alu, "stages": stage_rows,
+                    "alu": alu, "pmc": pmc_note, "library": lib_version, "stages": stage_rows,
                     "whole_view": {"algorithmic_bytes": ab["total"], "achieved": round(wv_ach, 1),
                                    "frac": round(wv_ach / HBM_PEAK_GBPS, 4),
+                                   "frac_without_replaced_stages": round(wv_kept / HBM_PEAK_GBPS, 4),
                                    # also against what a float4 copy reaches on this part (6.3 TB/s)
                                    "frac_of_copy_rate": round(wv_ach / 6300.0, 4),
                                    "traffic": total_traffic,
                                    "frac_traffic": round(total_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
                                    if total_traffic else None,
                                    "note": "frac counts the reference algorithm's bytes (incl. its 45-bit global sort, which "
-                                           "this pipeline replaces); frac_traffic counts the HBM bytes the PMC counters saw"}}
+                                           "this pipeline replaces); frac_without_replaced_stages leaves the replaced stages' bytes "
+                                           "out (same time); frac_traffic counts the HBM bytes the PMC counters saw"}}
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N == 1 only) + parity of the benchmarked run ------
     cpu_baseline = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dist_single:
         from oracle import saga_oracle as so
+        native = so.use_native_build()   # -O3 -march=native, compiled on THIS machine; same results
         if args.cpu_threads > 0:
             so.set_num_threads(args.cpu_threads)
         inp = so.Inputs(means3D=scene.means3D, opacities=scene.opacities, viewmatrix=cam.viewmatrix,
@@ -367,13 +409,18 @@ def main():
                         sh_degree=3 if fwd_only else 0, mask=np.ones(P, np.float32) if fwd_only else None,
                         scales=scene.scales, rotations=scene.rotations)
         dLn = dL.cpu().numpy()
-        c0 = time.perf_counter()
-        fo = so.forward(inp)
-        bo = None if fwd_only else so.backward(inp, fo, dLn)
-        cpu_s = time.perf_counter() - c0
+        nviews = max(1, args.cpu_views)
+        view_s = []
+        for _ in range(nviews):
+            c0 = time.perf_counter()
+            fo = so.forward(inp)
+            bo = None if fwd_only else so.backward(inp, fo, dLn)
+            view_s.append(time.perf_counter() - c0)
+        cpu_s = sum(view_s) / nviews
         cpu_baseline = {"value": round(1.0 / cpu_s, 4), "unit": "views/s", "cores": so.num_threads(), "kind": "port",
-                        "sample": f"1 full view {'fwd' if fwd_only else 'fwd+bwd'} of {args.config} (P={P}, {W}x{H}, C={C}) "
-                                  f"in {cpu_s:.2f} s, OpenMP over Gaussians/tiles, nproc={os.cpu_count()}"}
+                        "sample": f"{nviews} full views {'fwd' if fwd_only else 'fwd+bwd'} of {args.config} (P={P}, {W}x{H}, C={C}), "
+                                  f"{', '.join(f'{v:.2f}' for v in view_s)} s each, OpenMP over Gaussians/tiles, "
+                                  f"gcc -O3 {'-march=native' if native else '(portable build)'}, nproc={os.cpu_count()}"}
         # parity of what was just benchmarked (product default lists) against that oracle run
         step()
         torch.cuda.synchronize(dev)
@@ -422,7 +469,7 @@ def main():
         out = {
             "metric": names.get(args.config, f"train views/sec (fwd+bwd), {args.config}"),
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "timing": timing, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "parallelism": f"view-sharded x{world}", "counters": counters,
                        "lists": "lean (product default: only overlaps that pass the exact-conservative cull are listed; "

@@ -44,10 +44,41 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+_NATIVE = False
+
+
+def use_native_build() -> bool:
+    """the CPU BASELINE (bench.py's cpu_baseline leg) is timed with an `-O3 -march=native` build.  The portable
+    library under _build/ is compiled in the build container, whose CPU is not the GPU box's, so this compiles a second copy
+    ON THE MACHINE IT RUNS ON (same flags otherwise: no FMA contraction, no fast-math -- the results are the same), keyed by the
+    CPU's flag set.  Call before the first oracle call; returns False (and keeps the portable build) if gcc is unavailable."""
+    global _NATIVE, _LIB_PATH, _lib
+    import hashlib
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags"))
+    except Exception:  # noqa: BLE001
+        flags = "unknown"
+    tag = hashlib.sha1(flags.encode()).hexdigest()[:10]
+    path = os.path.join(_HERE, "_build", f"libsaga_rast_oracle_native_{tag}.so")
+    src = os.path.join(_HERE, "saga_rast_oracle.c")
+    try:
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                                   "-shared", "-o", path, src, "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:  # noqa: BLE001
+        return False
+    if _lib is not None and not _NATIVE:
+        _lib = None
+    _LIB_PATH, _NATIVE = path, True
+    return True
+
+
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not _NATIVE:
+            build()
         L = C.CDLL(_LIB_PATH)
         fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
         L.saga_oracle_forward.restype = vp

@@ -22,6 +22,23 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize"]
 
 
+def source_hash(extra_flags=()) -> str:
+    """Stamp of what a library is built from: the kernel sources, the C-ABI headers and the compiler flags.  Compiled into the
+    library (mi_rast_version()) so that measurements taken with one build -- profiles/traffic_*.json, alu_*.json -- are never
+    reported next to timings of another (bench.py prints null instead)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR) if f.endswith((".h", ".hip"))] + HEADERS):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    h.update(" ".join(list(HIPCC_FLAGS) + list(extra_flags)).encode())
+    return h.hexdigest()[:12]
+
+
+def _hash_flag(extra_flags=()):
+    return ['-DMI_RAST_SRC_HASH="' + source_hash(extra_flags) + '"']
+
+
 def find_hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if c and os.path.exists(c):
@@ -40,7 +57,7 @@ def is_stale() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp", os.path.join(SRC_DIR, "mi_rast.hip")]
+    cmd = [find_hipcc()] + HIPCC_FLAGS + _hash_flag() + ["-o", LIB_PATH + ".tmp", os.path.join(SRC_DIR, "mi_rast.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -55,7 +72,7 @@ def build_profiling_library(verbose: bool = False) -> str:
     """The same sources with -DMI_RAST_PROFILING: run-time ablation masks (MI_RAST_ABLATE / MI_RAST_ABLATE_FWD), in-kernel
     cycle counters, the VALU comparison kernels.  For tools/ only; the product library carries none of it.  Select it with
     MI_RAST_LIB=<path> (seganygaussians_amd/_lib.py)."""
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-DMI_RAST_PROFILING", "-o", PROF_LIB_PATH + ".tmp",
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-DMI_RAST_PROFILING"] + _hash_flag(["-DMI_RAST_PROFILING"]) + ["-o", PROF_LIB_PATH + ".tmp",
                                           os.path.join(SRC_DIR, "mi_rast.hip")]
     if verbose:
         print(" ".join(cmd))

@@ -625,7 +625,11 @@ void knn_launch(int rows, const float* query, int M, const KnnWs& w, int exclude
 extern "C" {
 
 const char* mi_rast_last_error(void) { return g_last_error.c_str(); }
-const char* mi_rast_version(void) { return "mi_rast 0.2 (gfx950)"; }
+#ifndef MI_RAST_SRC_HASH
+#define MI_RAST_SRC_HASH "unstamped"
+#endif
+// "... src:<hash>": seganygaussians_amd/build.py source_hash() of the sources, headers and flags this library was built from
+const char* mi_rast_version(void) { return "mi_rast 0.3 (gfx950) src:" MI_RAST_SRC_HASH; }
 
 int mi_rast_supported_channels(int* out, int n)
 {

@@ -246,6 +246,23 @@ def test_bench_single_rank_rccl_step():
     assert set(line["roofline"]["stages"]) >= {"preprocess", "blend_fwd", "blend_bwd", "geom_bwd"}
 
 
+def test_three_steps_on_single_rank_rccl_group():
+    """ViewShardedStep / allreduce_grads_async / set_features_ready_event through three consecutive steps with a feature update
+    in between, on a single-rank RCCL group (ordering bugs -- a blend stage that reads features before the update behind the
+    collective has landed, an event consumed by the wrong call -- show up at one rank too): the gradients of every step and the
+    final features equal those of a plain single-stream run.  tests/dist_steps_check.py does the work in a subprocess."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_steps_check.py")], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["moved"] > 1e-3 and min(r["step_change"]) > 1e-3, r       # the updates matter: a stale read would be visible
+    assert max(r["grad_rel"]) < 1e-5 and r["feat_rel"] < 1e-5, r
+
+
 @pytest.mark.parametrize("use_cov", [False, True])
 def test_backward_writes_every_gradient_row(use_cov):
     """include/mi_rast.h: only dL_dcolor / dL_dsh must be cleared by the caller; every other gradient output is written in

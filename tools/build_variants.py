@@ -16,7 +16,8 @@ from seganygaussians_amd import build as b  # noqa: E402
 def one(spec):
     name, _, flags = spec.partition("=")
     out = os.path.join(root, "seganygaussians_amd", f"libmi_rast_{name}.so")
-    cmd = [b.find_hipcc()] + b.HIPCC_FLAGS + [f for f in flags.split(",") if f] + ["-o", out, os.path.join(b.SRC_DIR, "mi_rast.hip")]
+    extra = [f for f in flags.split(",") if f]
+    cmd = [b.find_hipcc()] + b.HIPCC_FLAGS + extra + b._hash_flag(extra) + ["-o", out, os.path.join(b.SRC_DIR, "mi_rast.hip")]
     subprocess.check_call(cmd)
     return out
 

@@ -2,7 +2,10 @@
 """Turns gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/:
    profiles/<tag>_kernel_stats.md   per-kernel time table (rocprofv3 --kernel-trace --stats)
    profiles/<tag>_pmc.md            PMC counters of the hot kernels
-   profiles/traffic.json            HBM bytes per launch per stage (FETCH_SIZE / WRITE_SIZE passes), read by bench.py
+   profiles/traffic_<cfg>.json      HBM bytes per launch per stage (FETCH_SIZE / WRITE_SIZE passes), read by bench.py
+   profiles/alu_<cfg>.json          matrix / vector pipe busy fractions per stage (SQ passes), read by bench.py
+Both JSON files carry `_stamp` = mi_rast_version() of the library the passes ran with (a hash of sources, headers and flags);
+bench.py ignores them when another build is loaded.   python tools/summarize_profiles.py <tag> [cfg3|cfg2|cfg5]
 """
 import collections
 import csv
@@ -12,8 +15,10 @@ import re
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
+sfx = "" if cfg == "cfg3" else f"_{cfg}"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}{sfx}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -39,16 +44,17 @@ for r in rows:
     a = agg.setdefault(short(r["Name"]), [0, 0]); a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
 tot = sum(v[1] for v in agg.values())
 bench_line = open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1]
-with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as f:
+stamp = (json.loads(bench_line).get("roofline") or {}).get("library")
+with open(os.path.join(dst, f"{tag}_kernel_stats{sfx}.md"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats ({tag})\n\n")
-    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline` "
-            "on 1x MI355X (BASELINE cfg3: 1M Gaussians, 1920x1080, 32-D, fwd+bwd). Kernel names shortened; template "
+    f.write(f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --config {cfg} --steps 10 --warmup 2 --settle 0 "
+            f"--dist-blocks 0 --no-cpu-baseline` on 1x MI355X (BASELINE {cfg}); library `{stamp}`. Kernel names shortened; template "
             "instances of one kernel merged. Each bench step launches every kernel once; calls also include the warm-up, "
             "the per-stage timing steps and one counter step.\n\n")
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         f.write(f"| `{k}` | {c} | {t/1e6:.3f} | {t/c/1e3:.1f} | {100*t/tot:.2f} |\n")
-    f.write("\nUn-profiled bench line of the same build (`python bench.py --steps 20 --warmup 3`):\n\n```json\n" + bench_line + "\n```\n")
+    f.write(f"\nUn-profiled bench line of the same build (`python bench.py --config {cfg} --steps 20 --warmup 3`):\n\n```json\n" + bench_line + "\n```\n")
 
 
 def pmc(name):
@@ -66,8 +72,8 @@ def pmc(name):
 
 fetch, write = pmc("fetch"), pmc("write")
 traffic = {}
-with open(os.path.join(dst, f"{tag}_pmc.md"), "w") as f:
-    f.write(f"# rocprofv3 PMC passes ({tag})\n\nSeparate passes per counter group (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, two SQ groups), "
+with open(os.path.join(dst, f"{tag}_pmc{sfx}.md"), "w") as f:
+    f.write(f"# rocprofv3 PMC passes ({tag}, {cfg}, library {stamp})\n\nSeparate passes per counter group (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, two SQ groups), "
             "`--kernel-trace` only, same bench command. FETCH_SIZE / WRITE_SIZE are in KiB per dispatch (averaged over the "
             "dispatches of a kernel). Per `/opt/skills/guides/MI355X_MICROARCH.md` (HBM): on gfx950 FETCH_SIZE reports exactly "
             "half of the bytes of a wide coalesced stream (it tallies 128-B requests at 64 B), so `traffic = (2*FETCH_SIZE + "
@@ -105,11 +111,14 @@ for k in set(sq1) & set(sq2):
     simd_cycles = gui / 8.0 * 1024.0
     alu[st] = {"kernel": k, "mfma_busy_frac": round((mf or 0) / simd_cycles, 4), "valu_busy_frac": round(4.0 * (va or 0) / simd_cycles, 4),
                "lds_bank_conflict_frac": round((avg(sq2[k], "SQ_LDS_BANK_CONFLICT") or 0) / max(1.0, avg(sq2[k], "SQ_LDS_IDX_ACTIVE") or 1.0), 4),
-               "source": f"profiles/{tag}_pmc.md"}
-json.dump(alu, open(os.path.join(dst, "alu.json"), "w"), indent=1)
+               "source": f"profiles/{tag}_pmc{sfx}.md"}
+alu["_stamp"] = stamp
+alu["_source"] = f"profiles/{tag}_pmc{sfx}.md"
+json.dump(alu, open(os.path.join(dst, f"alu_{cfg}.json"), "w"), indent=1)
 for st in traffic.values():
     st["bytes_per_launch"] = round(st["bytes_per_launch"])
-traffic["_source"] = f"profiles/{tag}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note)"
-json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-print(open(os.path.join(dst, f"{tag}_kernel_stats.md")).read()[:3000])
+traffic["_source"] = f"profiles/{tag}_pmc{sfx}.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note)"
+traffic["_stamp"] = stamp
+json.dump(traffic, open(os.path.join(dst, f"traffic_{cfg}.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_kernel_stats{sfx}.md")).read()[:3000])
 print(json.dumps(traffic, indent=1))
