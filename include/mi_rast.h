@@ -58,6 +58,8 @@ extern "C" {
                                   the reference (n_contrib differs on ~1e-5 of the pixels, the per-row gradient noise is ~10x the
                                   reference's own; still inside the 1e-4 contract).  The backward MUST be given the flags of its
                                   forward: it re-takes the same decisions */
+#define MI_RAST_VERIFY_LISTS 16 /* debugging aid (lean lists only; synchronous): zero-fills the list entries before the emit pass and
+                                * fails with MI_RAST_ERR_HIP if a slot the count pass reserved was not written by the emit pass */
 #define MI_RAST_F32_BLEND 2    /* 32/64-channel forward on the f32 FMA-chain kernel instead of the exactly split bf16x3
                                   matrix kernel (same alpha/T/n_contrib bit for bit; images agree to a few ulp) */
 

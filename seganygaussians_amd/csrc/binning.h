@@ -756,6 +756,21 @@ __device__ __forceinline__ void emit_blend_list(SrcPtr sorted_entries, int m, ui
     if (tid == 0) blend_count[tile] = (uint32_t)m;
 }
 
+// MI_RAST_VERIFY_LISTS (include/mi_rast.h): the lean lists rest on the count pass and the emit pass taking bit-identical float
+// decisions in two template instances of bin_spans_kernel -- a tile is counted iff the emit pass stores an entry for it.  With
+// the flag the entries are zero-filled before the emit pass and this kernel counts the slots of every tile's segment that
+// are still zero afterwards (a lean entry always carries a non-zero quadrant mask): any such slot is a decision that differed.
+__global__ void __launch_bounds__(256) verify_entries_kernel(uint32_t ntiles, const uint2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ entries, uint32_t* __restrict__ unwritten)
+{
+    const uint32_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const uint2 r = ranges[tile];
+    uint32_t n = 0;
+    for (uint32_t i = r.x + threadIdx.x; i < r.y; i += 256) n += entries[i] == 0u;
+    if (n) atomicAdd(unwritten, n);
+}
+
 template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT, bool FULL = true>
 __global__ void __launch_bounds__(NT) tile_sort_kernel(uint32_t ntiles, const uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ entries,

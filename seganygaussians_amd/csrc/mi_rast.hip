@@ -140,6 +140,13 @@ struct HostSync {
         ok = true;
         return true;
     }
+    // (a host thread's scratch goes with the thread; errors are ignored: at process exit the runtime may be gone already)
+    ~HostSync()
+    {
+        if (ev) (void)hipEventDestroy(ev);
+        if (ev2) (void)hipEventDestroy(ev2);
+        if (pinned) (void)hipHostFree(pinned);
+    }
 };
 thread_local HostSync g_host_sync_tl[MAX_DEVICES];
 
@@ -471,7 +478,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     char* bin_base = binning_buffer(bin_size, binning_user);
     if (!bin_base) return fail(MI_RAST_ERR_ALLOC, "binning buffer callback returned NULL");
     bin = bin_from(bin_base, R);
+    const bool verify = !full && (flags & MI_RAST_VERIFY_LISTS) != 0;
     if (R > 0) {
+        if (verify) HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint32_t), stream));
         {
             StageTimer t(stream, MI_STAGE_EMIT);
             const size_t emit_lds = bin_lds + 8 * 1024 * sizeof(uint32_t);
@@ -490,6 +499,17 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             }
         }
         STAGE_CHECK("emit ranks");
+        if (verify) {   // debugging aid: synchronous
+            uint32_t* ctr = reinterpret_cast<uint32_t*>(img.num_rendered + R_SLOTS * R_SLOT_STRIDE + 2);
+            HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(verify_entries_kernel, dim3(ntiles), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges, bin.entries, ctr);
+            uint32_t unwritten = 0;
+            HIP_TRY(hipMemcpyAsync(&unwritten, ctr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (unwritten)
+                return fail(MI_RAST_ERR_HIP, "internal error: " + std::to_string(unwritten) + " list slots were counted but not emitted "
+                                             "(count / emit passes of bin_spans_kernel disagree)");
+        }
         int rank_bits = 1;
         while ((1ll << rank_bits) < (long long)P) rank_bits++;
         int passes = (rank_bits + 7) / 8;
@@ -526,6 +546,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     } else {
         // no overlap at all: the per-tile sort, which writes every tile's blend_count otherwise, does not run
         HIP_TRY(hipMemsetAsync(img.blend_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
+        // the range scan stores {total, longest list} into this thread's pinned words: never return while that store can still
+        // land (the next forward of this thread, on another stream, would read them)
+        HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
     }
     return MI_RAST_OK;
 }

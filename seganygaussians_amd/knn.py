@@ -60,6 +60,12 @@ class KnnIndex:
         if K < 1 or kt is None:
             raise RuntimeError(f"K must be between 1 and {_SUPPORTED_K[-1]}")
         q = None if query is None else _prep(query, "query points")
+        if q is not None and (q.dim() != 2 or q.size(1) != 3):
+            raise RuntimeError(f"query points must have shape (N, 3), got {tuple(q.shape)}")
+        if K > self.M - (1 if (q is None and exclude_self) else 0):
+            # fewer candidates than K: the kernels would pad with index -1 / distance 3.4e38, and `features[idx]` with -1 silently
+            # picks the LAST row under torch indexing -- refuse instead
+            raise RuntimeError(f"K = {K} neighbours requested from {self.M} reference points")
         rows = self.M if q is None else q.size(0)
         idx = torch.empty((rows, kt), dtype=torch.int64, device=self.device)
         d2 = torch.empty((rows, kt), dtype=torch.float32, device=self.device)

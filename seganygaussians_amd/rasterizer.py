@@ -108,15 +108,16 @@ _opts = _CallOptions()
 
 
 @contextlib.contextmanager
-def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None):
+def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None):
     """Within the block, forwards of this thread run with the given modes: `full_lists` materialises the reference's
     point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels, `no_cull` switches the exact-conservative cull off (testing aid), `fast_exp` evaluates exp() as
     v_exp_f32(x * log2e) instead of the device library's expf the reference's kernels call (+2 % views/s, ~5 ulp: a few
-    alpha >= 1/255 decisions differ from the reference's).  The flags of a
+    alpha >= 1/255 decisions differ from the reference's); `verify_lists` (debugging aid) checks that the count and emit passes of the
+    lean lists agree slot by slot.  The flags of a
     forward are remembered with its buffers and handed to its backward."""
     prev = _opts.flags
     for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend), (_lib.MI_RAST_NO_CULL, no_cull),
-                   (_lib.MI_RAST_FAST_EXP, fast_exp)):
+                   (_lib.MI_RAST_FAST_EXP, fast_exp), (_lib.MI_RAST_VERIFY_LISTS, verify_lists)):
         if v is not None:
             _opts.flags = (_opts.flags | bit) if v else (_opts.flags & ~bit)
     try:
@@ -129,6 +130,8 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
                                rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                image_height, image_width, sh, degree, campos, prefiltered, debug):
     """RasterizeGaussiansCUDA (CF/rasterize_points.cu:35-115; DEPTH/rasterize_points.cu:35-130)."""
+    ready = _opts.features_ready          # one-shot: consumed by THIS forward whatever happens below (P == 0, an exception)
+    _opts.features_ready = None
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     L = _lib.load()
@@ -149,8 +152,6 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
                                    viewmatrix, projmatrix, campos, mask)]
         bg_c, m3_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, vm_c, pm_c, cp_c, mk_c = t
         n = C.c_int(0)
-        ready = _opts.features_ready          # one-shot; cleared whatever happens below
-        _opts.features_ready = None
         if with_mask_depth and (mk_c is None or mk_c.numel() != P or not mk_c.is_cuda or mk_c.dtype != torch.float32):
             # the DEPTH package always passes a mask (DEPTH/.../__init__.py:323); without one out_mask / out_depth
             # would be left unwritten
@@ -284,6 +285,7 @@ def rasterize_mask_gaussians_native(means3D, opacity, mask, scales, rotations, s
                                     viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width,
                                     prefiltered, debug):
     """RasterizeMaskGaussiansCUDA (DEPTH/rasterize_points.cu, mask-only forward)."""
+    _opts.features_ready = None           # a features-ready event is for the next FEATURE forward of this thread: never left armed
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     L = _lib.load()

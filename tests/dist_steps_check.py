@@ -27,7 +27,7 @@ torch.cuda.set_device(dev)
 P, W, H, C, LR, STEPS = 60_000, 480, 272, 32, 50.0, 3
 sc = scenes.make_scene(P, W, H, 400.0, C, np.log(0.03), 0.7, seed=4)
 t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
-means3D, opac, scales, rots, feats0 = t(sc.means3D), t(sc.opacities), t(sc.scales), t(sc.rotations), t(sc.features)
+means3D, opac, scales, rots, feats0 = t(sc.means3D), t(sc.opacities).requires_grad_(True), t(sc.scales), t(sc.rotations), t(sc.features)
 dL = t(scenes.make_grad_image(C, H, W, seed=2))
 
 
@@ -38,18 +38,21 @@ def render_backward(feats, view):
                                        campos=t(cam.campos), prefiltered=False, debug=False)
     color, _ = GaussianRasterizer(st)(means3D=means3D, means2D=torch.zeros_like(means3D), shs=None, colors_precomp=feats, opacities=opac,
                                       scales=scales, rotations=rots, cov3D_precomp=None)
+    opac.grad = None
     torch.autograd.backward(color, grad_tensors=dL)
+    # what depends on the feature VALUES of this step (dL/dfeatures does not): the image and the opacity gradient
+    return color.detach().clone(), opac.grad.clone()
 
 
 def run(use_dist):
     feats = feats0.clone().requires_grad_(True)
-    grads = []
+    grads, images = [], []
     side = torch.cuda.Stream(device=dev)
     step = ViewShardedStep([feats])
     for k in range(STEPS):
         if use_dist:
             feats.grad = None
-            render_backward(feats, k)                       # (one view per rank and step: rank 0 of 1 renders view k)
+            images.append(render_backward(feats, k))        # (one view per rank and step: rank 0 of 1 renders view k)
             g = feats.grad
             ev, keep = allreduce_grads_async([g])
             with torch.cuda.stream(side):                    # the optimizer step: after the collective, off the compute stream
@@ -62,23 +65,31 @@ def run(use_dist):
             grads.append((g, upd))
         else:
             assert step.world_size == 1
-            step(1, lambda v: render_backward(feats, k))     # zeroes the grads, renders view k, (no-op) all-reduce
+            step(1, lambda v: images.append(render_backward(feats, k)))     # zeroes the grads, renders view k, (no-op) all-reduce
             feats.data.add_(feats.grad, alpha=-LR)
             grads.append((feats.grad, None))
     torch.cuda.synchronize(dev)
-    return [g.clone() for g, _ in grads], feats.detach().clone()
+    return [g.clone() for g, _ in grads], feats.detach().clone(), images
 
 
-plain_g, plain_f = run(False)
+plain_g, plain_f, plain_i = run(False)
 import torch.distributed as dist  # noqa: E402
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29547")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-dist_g, dist_f = run(True)
+dist_g, dist_f, dist_i = run(True)
 dist.destroy_process_group()
 rel = lambda a, b: float((a - b).norm() / b.norm())
+# how much the images would differ had a step read the features of the step before (same view, stale features)
+stale = []
+for k in range(1, STEPS):
+    f_prev = feats0.clone()
+    for j in range(k - 1):
+        f_prev.add_(plain_g[j], alpha=-LR)
+    stale.append(rel(render_backward(f_prev.requires_grad_(True), k)[0], plain_i[k][0]))
 out = {"grad_rel": [rel(a, b) for a, b in zip(dist_g, plain_g)], "feat_rel": rel(dist_f, plain_f),
-       "moved": rel(plain_f, feats0), "step_change": [rel(plain_g[k], plain_g[0]) for k in range(1, STEPS)]}
+       "image_rel": [rel(a[0], b[0]) for a, b in zip(dist_i, plain_i)], "dopacity_rel": [rel(a[1], b[1]) for a, b in zip(dist_i, plain_i)],
+       "moved": rel(plain_f, feats0), "stale_image_rel": stale}
 import ctypes  # noqa: E402
 ctypes.CDLL(None).fflush(None)
 print(json.dumps(out), flush=True)

@@ -96,11 +96,12 @@ class GpuRun:
         self.mask = t(inp.mask)
         self.with_mask = inp.mask is not None
 
-    def forward(self, debug=False, full_lists=True, f32_blend=None, no_cull=None, fast_exp=None):
+    def forward(self, debug=False, full_lists=True, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None):
         """full_lists=True materialises the reference's point_list / full-list positions (what the bit-exact
         comparisons with the oracle read); False is the product default ("lean" lists, include/mi_rast.h)."""
         i = self.inp
-        with self.R.forward_flags(full_lists=bool(full_lists), f32_blend=f32_blend, no_cull=no_cull, fast_exp=fast_exp):
+        with self.R.forward_flags(full_lists=bool(full_lists), f32_blend=f32_blend, no_cull=no_cull, fast_exp=fast_exp,
+                                  verify_lists=verify_lists):
             res = self.R.rasterize_gaussians_native(
                 i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
                 self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,
@@ -248,8 +249,9 @@ def compare_integer_path(gpu: GpuRun, fwd: so.ForwardOut):
 def compare_lean_with_full(inp, full: GpuRun, dL=None, dLm=None, full_grads=None, fast_exp=None):
     """The product default ("lean" lists) against the full-list run of the same input: identical blend lists
     (ids, quadrant masks, order), bit-identical images / final_T / radii; gradients equal up to the order of the
-    atomic float sums."""
-    lean = GpuRun(inp).forward(full_lists=False, fast_exp=fast_exp)
+    atomic float sums.  The lean run is made with MI_RAST_VERIFY_LISTS: every list slot the count pass reserved must have been
+    written by the emit pass (the two passes take their float decisions in two template instances of one kernel)."""
+    lean = GpuRun(inp).forward(full_lists=False, fast_exp=fast_exp, verify_lists=True)
     assert lean.num_rendered == full.num_rendered
     np.testing.assert_array_equal(lean.radii.cpu().numpy(), full.radii.cpu().numpy(), err_msg="radii (lean)")
     ids_l, qm_l, cnt_l = lean.blend_lists()

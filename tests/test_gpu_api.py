@@ -259,8 +259,9 @@ def test_three_steps_on_single_rank_rccl_group():
                          timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert r["moved"] > 1e-3 and min(r["step_change"]) > 1e-3, r       # the updates matter: a stale read would be visible
+    assert r["moved"] > 1e-3 and min(r["stale_image_rel"]) > 1e-3, r   # the updates matter: a stale read would be visible
     assert max(r["grad_rel"]) < 1e-5 and r["feat_rel"] < 1e-5, r
+    assert max(r["image_rel"]) < 1e-6 and max(r["dopacity_rel"]) < 1e-4, r
 
 
 @pytest.mark.parametrize("use_cov", [False, True])

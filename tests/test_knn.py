@@ -89,10 +89,16 @@ def test_knn_other_k_and_duplicates(K):
 
 
 def test_knn_fewer_references_than_k():
+    """K > M is refused: the kernels would pad with index -1, which `features[idx]` silently maps to the LAST row."""
     xyz = _cloud(3, 6, clustered=False)
-    idx, d2 = knn.KnnIndex(xyz).query(None, 4)
-    assert torch.equal(idx[:, 3], torch.full((3,), -1, device=DEV, dtype=torch.int64))
-    assert torch.equal(idx[:, :3].sort(1).values, torch.arange(3, device=DEV).expand(3, 3))
+    with pytest.raises(RuntimeError, match="neighbours requested from 3 reference points"):
+        knn.KnnIndex(xyz).query(None, 4)
+    with pytest.raises(RuntimeError, match="neighbours requested"):
+        knn.KnnIndex(xyz).query(None, 3, exclude_self=True)
+    idx, d2 = knn.KnnIndex(xyz).query(None, 3)
+    assert torch.equal(idx.sort(1).values, torch.arange(3, device=DEV).expand(3, 3))
+    with pytest.raises(RuntimeError, match="shape"):
+        knn.KnnIndex(xyz).query(torch.zeros(5, 2, device=DEV), 1)
 
 
 def test_dist_cuda2_matches_exhaustive_search():
