@@ -631,6 +631,43 @@ def _make_depth():
 _PLAIN_CACHE = {}
 
 
+def make_auto_rasterizer(default_channels: int = 32):
+    """The feature rasterizer with the channel count taken from the call: NUM_CHANNELS is a compile-time constant of the
+    reference's package (CF/cuda_rasterizer/config_contrastive_f.h:15 = 32; a user who trains 64-D features edits the header and
+    rebuilds), here a run-time argument of the C-ABI -- so the drop-in reads it off `colors_precomp` (or the background
+    colour when SH colours are given), falling back to `default_channels`.  Returns (rasterize_gaussians, GaussianRasterizer)
+    with the reference's signatures."""
+
+    def _channels(colors_precomp, raster_settings):
+        if colors_precomp is not None and torch.is_tensor(colors_precomp) and colors_precomp.dim() == 2 and colors_precomp.size(1) > 0:
+            return int(colors_precomp.size(1))
+        bg = getattr(raster_settings, "bg", None)
+        if torch.is_tensor(bg) and bg.numel() > 0:
+            return int(bg.numel())
+        return int(default_channels)
+
+    def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        return make_rasterizer(_channels(colors_precomp, raster_settings))[1](means3D, means2D, sh, colors_precomp, opacities, scales,
+                                                                             rotations, cov3Ds_precomp, raster_settings)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            with torch.no_grad():
+                rs = self.raster_settings
+                return mark_visible_native(positions, rs.viewmatrix, rs.projmatrix)
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+            impl = make_rasterizer(_channels(colors_precomp, self.raster_settings))[2](self.raster_settings)
+            return impl(means3D=means3D, means2D=means2D, opacities=opacities, shs=shs, colors_precomp=colors_precomp, scales=scales,
+                        rotations=rotations, cov3D_precomp=cov3D_precomp)
+
+    return rasterize_gaussians, GaussianRasterizer
+
+
 def make_rasterizer(channels: int):
     """(autograd Function, functional wrapper, nn.Module) for the plain C-channel rasterizer."""
     if channels not in _PLAIN_CACHE:

@@ -246,6 +246,31 @@ def test_bench_single_rank_rccl_step():
     assert set(line["roofline"]["stages"]) >= {"preprocess", "blend_fwd", "blend_bwd", "geom_bwd"}
 
 
+@pytest.mark.parametrize("C", [64, 48])
+def test_contrastive_dropin_takes_the_channel_count_from_the_call(C):
+    """The reference fixes NUM_CHANNELS when its extension is compiled; the drop-in reads it off `colors_precomp`: 64-D (one pass)
+    and 48-D (channel blocks 32 + 16) features through the unchanged import name, fwd + bwd against the oracle."""
+    import torch
+    import seganygaussians_amd
+    seganygaussians_amd.install_dropin()
+    from diff_gaussian_rasterization_contrastive_f import GaussianRasterizationSettings, GaussianRasterizer
+    inp = hp.make_inputs(3000, 160, 112, C, seed=70 + C, camera="orbit")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).cuda()
+    st = GaussianRasterizationSettings(image_height=inp.image_height, image_width=inp.image_width, tanfovx=inp.tanfovx, tanfovy=inp.tanfovy,
+                                       bg=t(inp.bg), scale_modifier=1.0, viewmatrix=t(inp.viewmatrix), projmatrix=t(inp.projmatrix),
+                                       sh_degree=0, campos=t(inp.campos), prefiltered=False, debug=False)
+    feats = t(inp.colors_precomp).requires_grad_(True)
+    means3D = t(inp.means3D)
+    color, radii = GaussianRasterizer(st)(means3D=means3D, means2D=torch.zeros_like(means3D), shs=None, colors_precomp=feats,
+                                          opacities=t(inp.opacities), scales=t(inp.scales), rotations=t(inp.rotations), cov3D_precomp=None)
+    assert color.shape == (C, inp.image_height, inp.image_width)
+    dL = scenes.make_grad_image(C, inp.image_height, inp.image_width, seed=4)
+    (color * t(dL)).sum().backward()
+    fwd = so.forward(inp)
+    hp.assert_close("color", color.detach().cpu().numpy(), fwd.color, flip_frac=hp.FLIP_FRAC)
+    hp.assert_close("dL_dfeatures", feats.grad.cpu().numpy(), so.backward(inp, fwd, dL).dL_dcolors, flip_frac=hp.GRAD_FLIP_FRAC)
+
+
 def test_three_steps_on_single_rank_rccl_group():
     """ViewShardedStep / allreduce_grads_async / set_features_ready_event through three consecutive steps with a feature update
     in between, on a single-rank RCCL group (ordering bugs -- a blend stage that reads features before the update behind the
