@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--fast-exp", action="store_true",
                     help="run the product in its MI_RAST_FAST_EXP mode (v_exp_f32 instead of expf; noted in "
                          "config.arithmetic -- the headline number is the default mode)")
+    ap.add_argument("--tile-fwd", action="store_true",
+                    help="A/B aid: 32/64-channel forward on the tile-batched kernel (MI_RAST_TILE_FWD) instead of the wave-per-quadrant one")
     ap.add_argument("--ref-on-gpu", action="store_true",
                     help="reporting only, after the timed region: also time oracle/_ref (the reference's own kernels, translated "
                          "test-only by oracle/build_ref.py) on the same workload and GPU")
@@ -169,8 +171,8 @@ def main():
     host_trace = [] if os.environ.get("MI_BENCH_HOST_TRACE") else None
 
     def step():
-        if args.fast_exp:
-            with R.forward_flags(fast_exp=True):
+        if args.fast_exp or args.tile_fwd:
+            with R.forward_flags(fast_exp=True if args.fast_exp else None, tile_fwd=True if args.tile_fwd else None):
                 return step_()
         return step_()
 

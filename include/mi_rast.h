@@ -60,6 +60,8 @@ extern "C" {
                                   forward: it re-takes the same decisions */
 #define MI_RAST_VERIFY_LISTS 16 /* debugging aid (lean lists only; synchronous): zero-fills the list entries before the emit pass and
                                 * fails with MI_RAST_ERR_HIP if a slot the count pass reserved was not written by the emit pass */
+#define MI_RAST_TILE_FWD 32    /* 32/64-channel forward on the tile-batched bf16x3 kernel (four lockstep waves per tile, blend_fwd_x3.h)
+                                  instead of the wave-per-quadrant kernel (blend_fwd_wave.h); same alpha/T/n_contrib bit for bit */
 #define MI_RAST_F32_BLEND 2    /* 32/64-channel forward on the f32 FMA-chain kernel instead of the exactly split bf16x3
                                   matrix kernel (same alpha/T/n_contrib bit for bit; images agree to a few ulp) */
 

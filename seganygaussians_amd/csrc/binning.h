@@ -111,7 +111,8 @@ constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
                                                            uint32_t big_threshold, int big_limit,
-                                                           uint32_t* __restrict__ big_list, int* __restrict__ host_out = nullptr)
+                                                           uint32_t* __restrict__ big_list, int* __restrict__ host_out = nullptr,
+                                                           uint32_t* __restrict__ zero_a = nullptr, uint32_t* __restrict__ zero_b = nullptr)
 {
     // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
     // one workgroup scan joins the pieces, and the ranges leave coalesced again.  Items below big_limit with more
@@ -156,6 +157,10 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uin
     for (int i = tid; i < ntiles; i += 1024) {
         const uint32_t lo = s_val[i], hi = s_val[i + 1];
         ranges[i] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+        if (zero_a != nullptr) {   // per-tile words a later kernel accumulates into with atomicMax (blend_fwd_wave.h)
+            zero_a[i] = 0u;
+            zero_b[i] = 0u;
+        }
         if (big_list != nullptr && i < big_limit && hi - lo > big_threshold) big_list[1 + atomicAdd(&s_nbig, 1u)] = (uint32_t)i;
     }
     __syncthreads();

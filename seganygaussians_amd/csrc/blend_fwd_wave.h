@@ -1,0 +1,299 @@
+// blend_fwd_wave.h -- forward blend for C = 32 / 64, one WAVE per 8x8 quadrant, no workgroup barriers.
+//
+// Same per-pixel arithmetic as blend_fwd_x3.h (renderCUDA<C> forward, CF/cuda_rasterizer/forward.cu:264-385: alpha, T, the
+// 1/255 and 1e-4 tests, n_contrib and final_T on f32 VALU code, bit-identical) and the same accumulation (every f32 operand
+// split exactly into three bf16 terms, six partial products on the bf16 matrix pipe, f32 accumulate).  What changes is who
+// walks the tile's blend list and when -- the restructuring blend_bwd_wave.h applied to the backward:
+//   * blend_fwd_x3.h stages the list in batches of 128 records for the whole tile: three workgroup barriers per batch, the
+//     four quadrant waves of a tile in lockstep (a batch lasts as long as its busiest quadrant), every quadrant's list padded
+//     to a multiple of 16 entries PER BATCH.  The kernel is VALU-bound (alpha evaluation: ~37 VALU per (wave, entry)) at four
+//     waves per SIMD, so every cycle a wave waits at a barrier is a cycle the SIMD has three waves to issue from;
+//   * here a workgroup IS one wave: it scans the tile's records itself (64 {id, position|mask} quarters per block, one block
+//     prefetched), queues the records of its quadrant in an LDS ring, and works through them in FULL groups of 16 entries
+//     -- only a wave's last group is padded.  The 16 records and feature rows of the NEXT group are requested before the
+//     current group is evaluated and wait in registers (2 + 2 C / 32 ... VGPRs); a wave leaves as soon as its 64 pixels are
+//     done.  The four quadrants of a tile are four workgroups on the same XCD (blockIdx -> (tile, quadrant) as in the backward).
+//   * the group's records sit at fixed LDS offsets (entry i at s_rec[i]): no per-quadrant index lists.
+#pragma once
+
+#include "blend_fwd_x3.h"
+
+namespace mirast {
+
+#ifndef MI_FWD_WAVES32
+#define MI_FWD_WAVES32 4   // waves per SIMD the 32-channel instance is compiled for (register budget 512 / waves)
+#endif
+#ifndef MI_FWD_WAVES64
+#define MI_FWD_WAVES64 3
+#endif
+
+template <int C, bool XEXP = false, bool STRIDED = false>
+__global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64) blend_fwd_wave_kernel(
+    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
+    int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed /* zeroed: receives atomicMax */,
+    uint32_t* __restrict__ tile_nsurv /* zeroed: receives atomicMax */, const float* __restrict__ bg_color,
+    float* __restrict__ out_color, int cstride_arg /* STRIDED: floats between feature rows (blend_fwd.h) */)
+{
+    static_assert(C == 32 || C == 64, "32-channel accumulator blocks");
+    constexpr int F4 = C / 4, NCB = C / 32, XROW = 6 * C, PLANE = 2 * C;  // float4s per row; channel blocks; row / plane bytes
+    constexpr int QCAP = 128;
+    constexpr int NK = XG * F4 / 64;   // float4 feature parts per lane and group
+    const int cstride = STRIDED ? cstride_arg : C;
+    __shared__ XRec s_rec[XG];
+    __shared__ uint4 s_feat4[XG * XROW / 16];
+    __shared__ uint2 s_queue[QCAP];     // {record index in the blend list, Gaussian id}
+    __shared__ uint32_t s_j[XG];        // blend-list index of the group's entries
+    static_assert(XG * XROW >= 8 * 65 * 4, "feature buffer too small for the epilogue transpose");
+    char* const featb = reinterpret_cast<char*>(s_feat4);
+    const char* const rec_bytes = reinterpret_cast<const char*>(s_rec);
+
+    // workgroup -> (tile, quadrant): every XCD works through a contiguous run of tiles, the four quadrants of a tile on four of
+    // its waves at about the same time (common.h; id = 8 (4 j + quad) + x: XCD x, j-th tile of its run)
+    uint32_t tile, quad;
+    {
+        const uint32_t b = blockIdx.x, x = b & 7u, jj = b >> 3;
+        const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
+        if ((jj >> 2) >= len) return;
+        tile = start + (jj >> 2);
+        quad = jj & 3u;
+    }
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
+    const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);
+    const uint32_t py = tile_y * TILE_Y + (quad >> 1) * 8 + (lane >> 3);
+    const uint32_t pix_id = W * py + px;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    bool done = !inside;
+
+    const uint2 range = ranges[tile];
+    const int list_len = (int)(range.y - range.x);
+    const bool any_inside = ballot64(inside) != 0;
+    const int ns = any_inside ? (int)blend_count[tile] : 0;
+    const BlendRec* rec = blend_rec + range.x;
+
+    float T = 1.0f;
+    uint32_t last_contributor = 0;
+    int consumed = any_inside ? list_len : 0;   // raw list entries this wave consumed (counter E of SURVEY.md 8d)
+    int walked = ns;                            // blend-list records it walked (the backward starts from there)
+    v16f acc0[NCB], acc1[NCB];  // pixels 0..31 / 32..63 of the quadrant x channels 32 cb + (lane & 31)
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            acc0[cb][r] = 0.f;
+            acc1[cb][r] = 0.f;
+        }
+    const bool lower = lane < 32;
+    const int chan2 = 2 * (lane & 31);  // byte offset of this lane's channel inside a bf16 plane
+
+    // ---- the queue of this quadrant's records
+    int scanned = 0, qh = 0, qt = 0;
+    uint2 scan_reg = make_uint2(0u, 0u);
+    if (ns > 0) scan_reg = reinterpret_cast<const uint2*>(rec + min(lane, ns - 1))[1];
+    auto consume_scan = [&]() {
+        const int j = scanned + lane;
+        const bool cand = j < ns && ((scan_reg.y >> quad) & 1u) != 0;
+        const uint64_t bal = ballot64(cand);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg.x);
+        qt += __builtin_popcountll(bal);
+        scanned += 64;
+        scan_reg = reinterpret_cast<const uint2*>(rec + min(scanned + lane, ns - 1))[1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    // Requests the rows queue[qh .. qh + n), n >= 1, of the next group: record quarter (lane & 3) of row (lane >> 2) and the
+    // feature parts.  Every lane loads (rows >= n repeat row n - 1 and are replaced by padding when the group is staged).
+    uint2 curq;
+    float4 featpf[NK];
+    auto request_rows = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const int rq = min(lane >> 2, n - 1), qq = lane & 3;
+            const uint32_t j = s_queue[(qh + rq) & (QCAP - 1)].x;
+            curq = reinterpret_cast<const uint2*>(rec + j)[qq];
+        }
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int e = lane + 64 * k;
+            const int g = min(e / F4, n - 1), part = e % F4;
+            const size_t gid = (size_t)s_queue[(qh + g) & (QCAP - 1)].y;
+            featpf[k] = reinterpret_cast<const float4*>(features + gid * (size_t)cstride)[part];
+        }
+    };
+
+    while (qt - qh < XG && scanned < ns) consume_scan();
+    int n = min(XG, qt - qh);
+    if (n > 0) request_rows(n);
+    uint64_t live = ballot64(!done);  // lanes still blending (wave-uniform copy of !done)
+    bool finished = false;
+
+    while (n > 0 && !finished) {
+        // ---- 1. the group's rows: registers -> LDS.  Rows beyond n (the wave's last group only) become padding: opacity 0
+        // (never blends) and zero features.
+        {
+            const int rq = lane >> 2, qq = lane & 3;
+            // quarter 0 = {x, y}; 1 = {id, pm} -> {position + 1, pm}; 2 = {a, b} -> {-a/2, -b}; 3 = {c, opacity} -> {-c/2, opacity}
+            float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
+            if (qq == 1) v = make_float2(__uint_as_float((curq.y >> 4) + 1u), __uint_as_float(curq.y));
+            if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
+            if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
+            if (rq >= n) {
+                v = make_float2(0.f, 0.f);
+                if (qq == 2) v = make_float2(-0.5f, 0.f);
+                if (qq == 3) v = make_float2(-0.5f, 0.f);
+            }
+            const int dst = qq == 0 ? 0 : (qq == 1 ? 24 : (qq == 2 ? 8 : 16));
+            *reinterpret_cast<float2*>(reinterpret_cast<char*>(&s_rec[rq]) + dst) = v;
+            if (qq == 1) s_j[rq] = s_queue[(qh + min(rq, n - 1)) & (QCAP - 1)].x;
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const int e = lane + 64 * k;
+                const int g = e / F4, part = e % F4;
+                uint2 hi = make_uint2(0u, 0u), mid = hi, lo = hi;
+                if (g < n) {
+                    split3_bf16x2(featpf[k].x, featpf[k].y, hi.x, mid.x, lo.x);
+                    split3_bf16x2(featpf[k].z, featpf[k].w, hi.y, mid.y, lo.y);
+                }
+                uint2* row = reinterpret_cast<uint2*>(featb + g * XROW);
+                row[part] = hi;
+                row[F4 + part] = mid;
+                row[2 * F4 + part] = lo;
+            }
+        }
+        qh += n;
+        // ---- 2. keep the queue ahead of the groups, then request the next group's rows: everything below runs while they travel
+        if (scanned < ns && qt - qh <= QCAP - 64) consume_scan();
+        while (qt - qh < XG && scanned < ns) consume_scan();
+        const int nnext = min(XG, qt - qh);
+        if (nnext > 0) request_rows(nnext);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        // ---- 3. alpha, T and w of the 16 entries (same f32 arithmetic as blend_fwd.h), w split and packed in pairs
+        uint32_t wp[3][XG / 2];
+        int fin_j = -1;
+#pragma unroll
+        for (int i = 0; i < XG / 2; i++) {
+            if (2 * i >= n || live == 0) {  // padding pair of the wave's last group, or every pixel is done (wave-uniform): w = 0
+                wp[0][i] = wp[1][i] = wp[2][i] = 0u;
+                continue;
+            }
+            float w2[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float4 p0 = *reinterpret_cast<const float4*>(rec_bytes + (2 * i + h) * (int)sizeof(XRec));
+                const float4 p1 = *reinterpret_cast<const float4*>(rec_bytes + (2 * i + h) * (int)sizeof(XRec) + 16);
+                const float dx = p0.x - pixfx, dy = p0.y - pixfy;
+                const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
+                const float t = p1.y * gauss_exp<XEXP>(power);
+                const float alpha = fminf(0.99f, t);
+                const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);
+                const float test_T = T * (1 - alpha);
+                // forward.cu:358-362: done once a contributor would push T below 1e-4 (that one is not blended).
+                const float tt = ok ? test_T : 1.0f;
+                live &= ~__builtin_amdgcn_fcmpf(tt, 0.0001f, 4 /* FCMP_OLT */);
+                const bool stop = tt < 0.0001f;
+                done = done || stop;
+                const bool blend = ok && !stop;
+                w2[h] = blend ? alpha * T : 0.f;
+                T = blend ? test_T : T;
+                last_contributor = blend ? __float_as_uint(p1.z) : last_contributor;
+                fin_j = (live == 0 && fin_j < 0) ? 2 * i + h : fin_j;  // first entry after which nobody is left
+            }
+            split3_bf16x2(w2[0], w2[1], wp[0][i], wp[1][i], wp[2][i]);
+            __builtin_amdgcn_sched_barrier(0);  // keeps the record reads of later pairs from piling up in registers
+        }
+        if (fin_j >= 0) {
+            consumed = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rec[fin_j].q1.z));
+            walked = (int)__builtin_amdgcn_readfirstlane(s_j[fin_j]) + 1;
+            finished = true;
+        }
+        // ---- 4. A operands (blend_fwd_x3.h): lane l and l ^ 32 exchange half of their packed terms
+        v4u A0[3], A1[3];
+        asm volatile("s_nop 3");
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(wp[p][d]), "+v"(wp[p][4 + d]));
+            A0[p] = (v4u){wp[p][0], wp[p][1], wp[p][2], wp[p][3]};
+            A1[p] = (v4u){wp[p][4], wp[p][5], wp[p][6], wp[p][7]};
+        }
+        // ---- 5. B operands: lane (channel, k half) gathers the three terms of its 8 entries' feature value (rows 8 khalf .. + 7)
+        const char* const fb = featb + (lower ? 0 : 8 * XROW) + chan2;
+#define X3_MFMA(ACC, AP, BP) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(AP), "v"(BP))
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            v4u B[3];
+            {
+                uint32_t bb[3][4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const char* r0 = fb + (2 * d) * XROW + 64 * cb;
+                    const char* r1 = fb + (2 * d + 1) * XROW + 64 * cb;
+#pragma unroll
+                    for (int p = 0; p < 3; p++)
+                        bb[p][d] = (uint32_t)*reinterpret_cast<const uint16_t*>(r0 + PLANE * p) |
+                                   ((uint32_t)*reinterpret_cast<const uint16_t*>(r1 + PLANE * p) << 16);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; p++) B[p] = (v4u){bb[p][0], bb[p][1], bb[p][2], bb[p][3]};
+            }
+            X3_MFMA(acc0[cb], A0[1], B[1]);
+            X3_MFMA(acc1[cb], A1[1], B[1]);
+            X3_MFMA(acc0[cb], A0[2], B[0]);
+            X3_MFMA(acc1[cb], A1[2], B[0]);
+            X3_MFMA(acc0[cb], A0[0], B[2]);
+            X3_MFMA(acc1[cb], A1[0], B[2]);
+            X3_MFMA(acc0[cb], A0[1], B[0]);
+            X3_MFMA(acc1[cb], A1[1], B[0]);
+            X3_MFMA(acc0[cb], A0[0], B[1]);
+            X3_MFMA(acc1[cb], A1[0], B[1]);
+            X3_MFMA(acc0[cb], A0[0], B[0]);
+            X3_MFMA(acc1[cb], A1[0], B[0]);
+        }
+#undef X3_MFMA
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // operand reads before the next group's rows land in the same LDS
+        n = nnext;
+    }
+
+    if (lane == 0 && any_inside) {
+        atomicMax(&tile_consumed[tile], (uint32_t)consumed);
+        atomicMax(&tile_nsurv[tile], (uint32_t)walked);
+    }
+    const size_t HW = (size_t)H * W;
+    if (inside) {
+        final_T[pix_id] = T;
+        n_contrib[pix_id] = last_contributor;
+    }
+    // accumulator tiles: lane l holds channel (l & 31); register r of block b <-> pixel 32 b + (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+    // (tools/mfma_probe.hip).  Transposed through LDS, 8 channels at a time, then stored pixel-major.
+    float* tp = reinterpret_cast<float*>(s_feat4);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+#pragma unroll
+        for (int part = 0; part < 4; part++) {
+            const int chl = lane & 31;
+            if ((chl >> 3) == part) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int L = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    tp[(chl & 7) * 65 + L] = acc0[cb][r];
+                    tp[(chl & 7) * 65 + 32 + L] = acc1[cb][r];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (inside) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int ch = 32 * cb + 8 * part + c;
+                    out_color[ch * HW + pix_id] = tp[c * 65 + lane] + T * bg_color[ch];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+    }
+}
+
+}  // namespace mirast

@@ -26,6 +26,7 @@
 #endif
 #include "blend_bwd_wave.h"
 #include "blend_fwd.h"
+#include "blend_fwd_wave.h"
 #include "blend_fwd_x3.h"
 #include "common.h"
 #include "contrastive.h"
@@ -460,7 +461,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                            img.tile_count, img.tile_cursor);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)ntiles + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
                            img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr,
-                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE);
+                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv);
     }
     STAGE_CHECK("tile scan");
     HIP_TRY(hipEventRecord(g_host_sync.ev2, stream));
@@ -586,6 +587,27 @@ void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs
         else X3_LAUNCH(false, true);
     }
 #undef X3_LAUNCH
+}
+
+// One wave per (tile, quadrant): 32 x the longest XCD run of tiles workgroups (blend_fwd_wave.h).
+template <int C>
+void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const float* features,
+                           const float* bg, float* out_color, bool xexp, int cstride)
+{
+    const uint32_t nt = vp.grid_x * vp.grid_y;
+    const uint32_t grid = 32u * ((nt + 7u) >> 3);
+#define FW_LAUNCH(XE, ST)                                                                                                     \
+    hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XE, ST>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec,            \
+                       img.blend_count, vp.W, vp.H, vp.grid_x, nt, features, img.final_T, img.n_contrib, img.tile_consumed,       \
+                       img.tile_nsurv, bg, out_color, cstride)
+    if (cstride == C) {
+        if (xexp) FW_LAUNCH(true, false);
+        else FW_LAUNCH(false, false);
+    } else {
+        if (xexp) FW_LAUNCH(true, true);
+        else FW_LAUNCH(false, true);
+    }
+#undef FW_LAUNCH
 }
 
 template <int C, bool MASKGRAD>
@@ -959,6 +981,7 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
             // feature channels in blocks of 64 / 32 / 16 (one launch per block; see channels_supported)
             const size_t HW = (size_t)width * height;
             const bool f32_blend = (flags & MI_RAST_F32_BLEND) != 0;   // f32 FMA-chain forward (include/mi_rast.h)
+            const bool tile_fwd = (flags & MI_RAST_TILE_FWD) != 0;     // the tile-batched bf16x3 forward (blend_fwd_x3.h) instead of the wave kernel
             for (int c0 = 0; c0 < channels;) {
                 const int cb = channel_block(channels - c0);
                 const float* f = feature_ptr + c0;
@@ -966,10 +989,12 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
                 float* out = out_color + (size_t)c0 * HW;
                 if (cb == 64) {
                     if (f32_blend) launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
-                    else launch_blend_fwd_x3<64>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                    else if (tile_fwd) launch_blend_fwd_x3<64>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                    else launch_blend_fwd_wave<64>(vp, stream, img, bin, f, bgp, out, xexp, channels);
                 } else if (cb == 32) {
                     if (f32_blend) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
-                    else launch_blend_fwd_x3<32>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                    else if (tile_fwd) launch_blend_fwd_x3<32>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                    else launch_blend_fwd_wave<32>(vp, stream, img, bin, f, bgp, out, xexp, channels);
                 } else {
                     launch_blend_fwd<16, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
                 }

@@ -108,7 +108,7 @@ _opts = _CallOptions()
 
 
 @contextlib.contextmanager
-def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None):
+def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None):
     """Within the block, forwards of this thread run with the given modes: `full_lists` materialises the reference's
     point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels, `no_cull` switches the exact-conservative cull off (testing aid), `fast_exp` evaluates exp() as
     v_exp_f32(x * log2e) instead of the device library's expf the reference's kernels call (+2 % views/s, ~5 ulp: a few
@@ -117,7 +117,8 @@ def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, 
     forward are remembered with its buffers and handed to its backward."""
     prev = _opts.flags
     for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend), (_lib.MI_RAST_NO_CULL, no_cull),
-                   (_lib.MI_RAST_FAST_EXP, fast_exp), (_lib.MI_RAST_VERIFY_LISTS, verify_lists)):
+                   (_lib.MI_RAST_FAST_EXP, fast_exp), (_lib.MI_RAST_VERIFY_LISTS, verify_lists),
+                   (_lib.MI_RAST_TILE_FWD, tile_fwd)):
         if v is not None:
             _opts.flags = (_opts.flags | bit) if v else (_opts.flags & ~bit)
     try:
