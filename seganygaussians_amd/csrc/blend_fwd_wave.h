@@ -297,3 +297,177 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
 }
 
 }  // namespace mirast
+
+namespace mirast {
+
+// The same walk for RGB (C = 3; EXTRA = 2: the DEPTH variant's mask and depth planes, DEPTH/cuda_rasterizer/forward.cu:308-309,
+// 363-365, 384-385, no background term on them): accumulators on the VALU (acc[ch] = fmaf(f[ch], w, acc[ch]) in list order --
+// the arithmetic of blend_fwd.h, bit for bit), the 16 rows of a group staged as {r, g, b, mask, depth} floats.
+template <int EXTRA, bool XEXP = false>
+__global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
+    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
+    int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features /* [P,3] */,
+    const float* __restrict__ mask, const float* __restrict__ depths, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed, uint32_t* __restrict__ tile_nsurv,
+    const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_mask, float* __restrict__ out_depth)
+{
+    constexpr int C = 3, CE = C + EXTRA, QCAP = 128, FROW = 8;
+    __shared__ XRec s_rec[XG];
+    __shared__ float s_f[XG * FROW];
+    __shared__ uint2 s_queue[QCAP];
+    __shared__ uint32_t s_j[XG];
+    const char* const rec_bytes = reinterpret_cast<const char*>(s_rec);
+
+    uint32_t tile, quad;
+    {
+        const uint32_t b = blockIdx.x, x = b & 7u, jj = b >> 3;
+        const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
+        if ((jj >> 2) >= len) return;
+        tile = start + (jj >> 2);
+        quad = jj & 3u;
+    }
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
+    const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);
+    const uint32_t py = tile_y * TILE_Y + (quad >> 1) * 8 + (lane >> 3);
+    const uint32_t pix_id = W * py + px;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    bool done = !inside;
+
+    const uint2 range = ranges[tile];
+    const int list_len = (int)(range.y - range.x);
+    const bool any_inside = ballot64(inside) != 0;
+    const int ns = any_inside ? (int)blend_count[tile] : 0;
+    const BlendRec* rec = blend_rec + range.x;
+
+    float T = 1.0f;
+    uint32_t last_contributor = 0;
+    int consumed = any_inside ? list_len : 0;
+    int walked = ns;
+    float acc[CE];
+#pragma unroll
+    for (int ch = 0; ch < CE; ch++) acc[ch] = 0.f;
+
+    int scanned = 0, qh = 0, qt = 0;
+    uint2 scan_reg = make_uint2(0u, 0u);
+    if (ns > 0) scan_reg = reinterpret_cast<const uint2*>(rec + min(lane, ns - 1))[1];
+    auto consume_scan = [&]() {
+        const int j = scanned + lane;
+        const bool cand = j < ns && ((scan_reg.y >> quad) & 1u) != 0;
+        const uint64_t bal = ballot64(cand);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg.x);
+        qt += __builtin_popcountll(bal);
+        scanned += 64;
+        scan_reg = reinterpret_cast<const uint2*>(rec + min(scanned + lane, ns - 1))[1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    // next group's rows: record quarter (lane & 3) of row (lane >> 2); lane l feeds value (l & 7) of row (l >> 3) and (l >> 3) + 8
+    uint2 curq;
+    float fpf[2];
+    auto request_rows = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const int rq = min(lane >> 2, n - 1), qq = lane & 3;
+            const uint32_t j = s_queue[(qh + rq) & (QCAP - 1)].x;
+            curq = reinterpret_cast<const uint2*>(rec + j)[qq];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int g = min((lane >> 3) + 8 * k, n - 1), c = lane & 7;
+            const size_t gid = (size_t)s_queue[(qh + g) & (QCAP - 1)].y;
+            float v = 0.f;
+            if (c < C) v = features[gid * 3 + c];
+            else if (EXTRA >= 1 && c == C) v = mask[gid];
+            else if (EXTRA >= 2 && c == C + 1) v = depths[gid];
+            fpf[k] = v;
+        }
+    };
+
+    while (qt - qh < XG && scanned < ns) consume_scan();
+    int n = min(XG, qt - qh);
+    if (n > 0) request_rows(n);
+    uint64_t live = ballot64(!done);
+    bool finished = false;
+
+    while (n > 0 && !finished) {
+        {
+            const int rq = lane >> 2, qq = lane & 3;
+            float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
+            if (qq == 1) v = make_float2(__uint_as_float((curq.y >> 4) + 1u), __uint_as_float(curq.y));
+            if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
+            if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
+            if (rq >= n) {
+                v = make_float2(0.f, 0.f);
+                if (qq == 2) v = make_float2(-0.5f, 0.f);
+                if (qq == 3) v = make_float2(-0.5f, 0.f);
+            }
+            const int dst = qq == 0 ? 0 : (qq == 1 ? 24 : (qq == 2 ? 8 : 16));
+            *reinterpret_cast<float2*>(reinterpret_cast<char*>(&s_rec[rq]) + dst) = v;
+            if (qq == 1) s_j[rq] = s_queue[(qh + min(rq, n - 1)) & (QCAP - 1)].x;
+#pragma unroll
+            for (int k = 0; k < 2; k++) s_f[((lane >> 3) + 8 * k) * FROW + (lane & 7)] = fpf[k];
+        }
+        qh += n;
+        if (scanned < ns && qt - qh <= QCAP - 64) consume_scan();
+        while (qt - qh < XG && scanned < ns) consume_scan();
+        const int nnext = min(XG, qt - qh);
+        if (nnext > 0) request_rows(nnext);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        int fin_j = -1;
+#pragma unroll
+        for (int i = 0; i < XG; i++) {
+            if (i >= n || live == 0) continue;   // padding of the wave's last group, or every pixel is done (wave-uniform)
+            const float4 p0 = *reinterpret_cast<const float4*>(rec_bytes + i * (int)sizeof(XRec));
+            const float4 p1 = *reinterpret_cast<const float4*>(rec_bytes + i * (int)sizeof(XRec) + 16);
+            const float dx = p0.x - pixfx, dy = p0.y - pixfy;
+            const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
+            const float t = p1.y * gauss_exp<XEXP>(power);
+            const float alpha = fminf(0.99f, t);
+            const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);
+            const float test_T = T * (1 - alpha);
+            const float tt = ok ? test_T : 1.0f;
+            live &= ~__builtin_amdgcn_fcmpf(tt, 0.0001f, 4 /* FCMP_OLT */);
+            const bool stop = tt < 0.0001f;
+            done = done || stop;
+            const bool blend = ok && !stop;
+            const float w = blend ? alpha * T : 0.f;
+            if (ballot64(blend) != 0) {
+                const float4 f0 = *reinterpret_cast<const float4*>(&s_f[i * FROW]);
+                acc[0] = fmaf(f0.x, w, acc[0]);
+                acc[1] = fmaf(f0.y, w, acc[1]);
+                acc[2] = fmaf(f0.z, w, acc[2]);
+                if constexpr (EXTRA >= 1) acc[3] = fmaf(f0.w, w, acc[3]);
+                if constexpr (EXTRA >= 2) acc[4] = fmaf(s_f[i * FROW + 4], w, acc[4]);
+            }
+            T = blend ? test_T : T;
+            last_contributor = blend ? __float_as_uint(p1.z) : last_contributor;
+            fin_j = (live == 0 && fin_j < 0) ? i : fin_j;
+        }
+        if (fin_j >= 0) {
+            consumed = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rec[fin_j].q1.z));
+            walked = (int)__builtin_amdgcn_readfirstlane(s_j[fin_j]) + 1;
+            finished = true;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        n = nnext;
+    }
+
+    if (lane == 0 && any_inside) {
+        atomicMax(&tile_consumed[tile], (uint32_t)consumed);
+        atomicMax(&tile_nsurv[tile], (uint32_t)walked);
+    }
+    const size_t HW = (size_t)H * W;
+    if (inside) {
+        final_T[pix_id] = T;
+        n_contrib[pix_id] = last_contributor;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix_id] = acc[ch] + T * bg_color[ch];
+        if constexpr (EXTRA >= 1) out_mask[pix_id] = acc[C];
+        if constexpr (EXTRA >= 2) out_depth[pix_id] = acc[C + 1];
+    }
+}
+
+}  // namespace mirast

@@ -71,15 +71,15 @@ __device__ __forceinline__ void cov2d_common(const float3& mean, const ViewParam
 }
 
 // CF/cuda_rasterizer/forward.cu:23-74
-__device__ __forceinline__ float3 computeColorFromSH(int idx, int deg, int max_coeffs, const float3 pos, const ViewParams& vp,
-                                                     const float* shs, uint8_t* clamped)
+// `sh`: the Gaussian's (max_coeffs, 3) coefficient row -- in the forward pass a row of the workgroup's LDS copy (below).
+__device__ __forceinline__ float3 computeColorFromSH(int idx, int deg, const float3 pos, const ViewParams& vp,
+                                                     const float* sh, uint8_t* clamped)
 {
     float3 dir = make_float3(pos.x - vp.campos[0], pos.y - vp.campos[1], pos.z - vp.campos[2]);
     float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
     dir.x = dir.x / len;
     dir.y = dir.y / len;
     dir.z = dir.z / len;
-    const float* sh = shs + (size_t)idx * max_coeffs * 3;
     const float x = dir.x, y = dir.y, z = dir.z;
     float res[3];
 #pragma unroll
@@ -124,6 +124,26 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int* __restrict__ r_slots, int prefiltered, int* __restrict__ culled_prefiltered)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // SH colours (forward.cu:23-74 reads 3 M floats per Gaussian, 192 bytes at degree 3): a thread walking its own row makes
+    // every load instruction of the wave touch 64 rows 192 bytes apart.  The workgroup's rows are one contiguous block of
+    // memory: staged into LDS with coalesced 16-byte loads (culled Gaussians included: 25 % more bytes, all of them streamed),
+    // read back per thread at a row stride padded to 3 M + 4 floats (b128 reads of 64 rows then cover all banks evenly).
+    extern __shared__ float s_sh[];
+    const int sh_row = 3 * M + 4;
+    if (!colors_given) {
+        const int rows = min((int)blockDim.x, P - (int)(blockIdx.x * blockDim.x));
+        const size_t base = (size_t)blockIdx.x * blockDim.x * 3 * M;
+        const int nfl = rows * 3 * M;
+        if ((3 * M) % 4 == 0 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0) {
+            for (int i = 4 * (int)threadIdx.x; i < nfl; i += 4 * (int)blockDim.x) {
+                const float4 v = *reinterpret_cast<const float4*>(shs + base + i);
+                *reinterpret_cast<float4*>(&s_sh[(i / (3 * M)) * sh_row + i % (3 * M)]) = v;
+            }
+        } else {
+            for (int i = (int)threadIdx.x; i < nfl; i += (int)blockDim.x) s_sh[(i / (3 * M)) * sh_row + i % (3 * M)] = shs[base + i];
+        }
+        __syncthreads();
+    }
     int my_radii = 0;
     uint32_t my_tiles = 0;
     uint32_t my_key = 0xFFFFFFFFu;
@@ -167,7 +187,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         if ((rmax.x - rmin.x) * (rmax.y - rmin.y) == 0) break;
 
         if (!colors_given) {
-            const float3 col = computeColorFromSH(idx, D, M, p_orig, vp, shs, clamped);
+            const float3 col = computeColorFromSH(idx, D, p_orig, vp, s_sh + threadIdx.x * sh_row, clamped);
             rgb[idx * 3 + 0] = col.x;
             rgb[idx * 3 + 1] = col.y;
             rgb[idx * 3 + 2] = col.z;

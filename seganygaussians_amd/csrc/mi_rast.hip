@@ -371,7 +371,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
         HIP_TRY(hipMemsetAsync(img.num_rendered, 0, R_SLOTS * R_SLOT_STRIDE * sizeof(int), stream));
-        hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, scales,
+        // SH colours: the workgroup's coefficient rows are staged in LDS (geometry.h), 256 rows of 3 M + 4 floats
+        const size_t sh_lds = colors_given ? 0 : (size_t)256 * (3 * (size_t)M + 4) * sizeof(float);
+        if (sh_lds > 64 * 1024) return fail(MI_RAST_ERR_INVALID, "too many SH coefficients per Gaussian (at most 16: degree 3)");
+        hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), sh_lds, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
                            geom.depth_key, geom.index_rec, img.num_rendered, prefiltered, cull_counter);
@@ -608,6 +611,23 @@ void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPt
         else FW_LAUNCH(false, true);
     }
 #undef FW_LAUNCH
+}
+
+template <int EXTRA>
+void launch_blend_fwd_wave_rgb(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const GeomPtrs& geom,
+                               const float* features, const float* mask, const float* bg, float* out_color, float* out_mask,
+                               float* out_depth, bool xexp)
+{
+    const uint32_t nt = vp.grid_x * vp.grid_y;
+    const uint32_t grid = 32u * ((nt + 7u) >> 3);
+    if (xexp)
+        hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, true>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec, img.blend_count,
+                           vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,
+                           img.tile_nsurv, bg, out_color, out_mask, out_depth);
+    else
+        hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, false>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec, img.blend_count,
+                           vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,
+                           img.tile_nsurv, bg, out_color, out_mask, out_depth);
 }
 
 template <int C, bool MASKGRAD>
@@ -975,8 +995,11 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
     {
         StageTimer t(stream, MI_STAGE_BLEND_FWD);
         const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;
-        if (mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
-        else if (channels == 3) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
+        const bool tile_fwd_rgb = (flags & MI_RAST_TILE_FWD) != 0;   // the tile-batched kernels instead of the wave-per-quadrant ones
+        if (mask && tile_fwd_rgb) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
+        else if (mask) launch_blend_fwd_wave_rgb<2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
+        else if (channels == 3 && tile_fwd_rgb) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
+        else if (channels == 3) launch_blend_fwd_wave_rgb<0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
         else {
             // feature channels in blocks of 64 / 32 / 16 (one launch per block; see channels_supported)
             const size_t HW = (size_t)width * height;
