@@ -38,7 +38,7 @@ struct FeatStage {
 };
 
 template <int C, int EXTRA, bool XEXP = false>
-__global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 5 : 1) blend_fwd_kernel(
+__global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fwd_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
     int W, int H, const float* __restrict__ features, const float* __restrict__ mask, const float* __restrict__ depths,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed,

@@ -96,12 +96,12 @@ class GpuRun:
         self.mask = t(inp.mask)
         self.with_mask = inp.mask is not None
 
-    def forward(self, debug=False, full_lists=True, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None):
+    def forward(self, debug=False, full_lists=True, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None):
         """full_lists=True materialises the reference's point_list / full-list positions (what the bit-exact
         comparisons with the oracle read); False is the product default ("lean" lists, include/mi_rast.h)."""
         i = self.inp
         with self.R.forward_flags(full_lists=bool(full_lists), f32_blend=f32_blend, no_cull=no_cull, fast_exp=fast_exp,
-                                  verify_lists=verify_lists):
+                                  verify_lists=verify_lists, tile_fwd=tile_fwd):
             res = self.R.rasterize_gaussians_native(
                 i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
                 self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,
@@ -198,7 +198,9 @@ class GpuRun:
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         return dict(final_T=self._view(self.img, off["final_T"], W * H, np.float32),
                     n_contrib=self._view(self.img, off["n_contrib"], W * H, np.uint32),
-                    ranges=self._view(self.img, off["ranges"], 2 * tiles, np.uint32))
+                    ranges=self._view(self.img, off["ranges"], 2 * tiles, np.uint32),
+                    tile_consumed=self._view(self.img, off["tile_consumed"], tiles, np.uint32),
+                    tile_nsurv=self._view(self.img, off["tile_nsurv"], tiles, np.uint32))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -63,10 +63,11 @@ def test_features32_dense():
 
 @pytest.mark.parametrize("C", [32, 64])
 def test_features_forward_x3_matches_f32_mfma(C):
-    """The default 32 / 64-channel forward accumulates on the bf16 matrix pipe with exactly split operands (blend_fwd_x3.h);
-    the MI_RAST_F32_BLEND flag selects the f32-MFMA kernel (a bit-exact fmaf chain).  Same lists, same alpha / T / n_contrib
-    (bit-identical), and images that differ by rounding of the f32 accumulation only (a few ulp; same distance from the
-    fp64-accumulating oracle)."""
+    """The default 32 / 64-channel forward (blend_fwd_wave.h: one wave per quadrant) accumulates on the bf16 matrix pipe with
+    exactly split operands; MI_RAST_TILE_FWD selects the tile-batched kernel with the same accumulation (blend_fwd_x3.h, round 2's
+    default), MI_RAST_F32_BLEND the f32-MFMA kernel (a bit-exact fmaf chain).  Same lists, same alpha / T / n_contrib and the same
+    per-tile walk counters (bit-identical), and images that differ by rounding of the f32 accumulation only (a few ulp; same
+    distance from the fp64-accumulating oracle)."""
     inp = hp.make_inputs(60_000, 640, 360, C, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
     x3 = hp.GpuRun(inp).forward()
     f32 = hp.GpuRun(inp).forward(f32_blend=True)
@@ -82,6 +83,15 @@ def test_features_forward_x3_matches_f32_mfma(C):
     ia, ib = x3.img_fields(), f32.img_fields()
     np.testing.assert_array_equal(ia["final_T"].view(np.uint32), ib["final_T"].view(np.uint32))
     np.testing.assert_array_equal(ia["n_contrib"], ib["n_contrib"])
+    tile = hp.GpuRun(inp).forward(tile_fwd=True)
+    c = tile.color.cpu().numpy().astype(np.float64)
+    assert np.abs(c - a).max() <= 2e-6 * scale and np.sqrt(((c - ref) ** 2).mean()) <= 1e-7 * scale
+    ic = tile.img_fields()
+    np.testing.assert_array_equal(ia["final_T"].view(np.uint32), ic["final_T"].view(np.uint32))
+    np.testing.assert_array_equal(ia["n_contrib"], ic["n_contrib"])
+    for k in ("tile_consumed", "tile_nsurv"):   # the wave kernel gathers them with atomicMax over the four quadrant waves
+        np.testing.assert_array_equal(ia[k], ic[k], err_msg=k)
+        np.testing.assert_array_equal(ia[k], ib[k], err_msg=k)
 
 
 def test_features32_odd_size_random_bg():

@@ -31,7 +31,7 @@ def short(n):
     return n[:90]
 
 
-STAGE_OF = {"blend_bwd_wave_kernel": "blend_bwd", "blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_mfma_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "blend_fwd_x3_kernel": "blend_fwd",
+STAGE_OF = {"blend_bwd_wave_kernel": "blend_bwd", "blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_mfma_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "blend_fwd_x3_kernel": "blend_fwd", "blend_fwd_wave_kernel": "blend_fwd", "blend_fwd_wave_rgb_kernel": "blend_fwd",
             "preprocess_fwd_kernel": "preprocess", "bin_spans_kernel<true>": "emit", "bin_spans_kernel<false>": "tile_scan", "bin_ranks_kernel<true, false>": "emit", "bin_ranks_kernel<true, false, false>": "emit",
             "tile_sort_kernel": "tile_sort",
             "bin_ranks_kernel<false, false>": "tile_scan", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
