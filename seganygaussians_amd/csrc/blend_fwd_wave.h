@@ -20,6 +20,27 @@
 
 namespace mirast {
 
+// workgroup -> (tile, quadrant): every XCD works through a contiguous run of tiles, the four quadrants of a tile on four of its
+// waves at about the same time (common.h; id = 8 (4 j + quad) + x: XCD x, j-th tile of its run).  MI_FWD_MAP = 1 (A/B): tile = id / 4.
+#ifndef MI_FWD_MAP
+#define MI_FWD_MAP 0
+#endif
+__device__ __forceinline__ bool fwd_wave_item(uint32_t b, uint32_t ntiles, uint32_t& tile, uint32_t& quad)
+{
+#if MI_FWD_MAP == 1
+    tile = b >> 2;
+    quad = b & 3u;
+    return tile < ntiles;
+#else
+    const uint32_t x = b & 7u, jj = b >> 3;
+    const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
+    if ((jj >> 2) >= len) return false;
+    tile = start + (jj >> 2);
+    quad = jj & 3u;
+    return true;
+#endif
+}
+
 #ifndef MI_FWD_WAVES32
 #define MI_FWD_WAVES32 4   // waves per SIMD the 32-channel instance is compiled for (register budget 512 / waves)
 #endif
@@ -48,16 +69,8 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
     char* const featb = reinterpret_cast<char*>(s_feat4);
     const char* const rec_bytes = reinterpret_cast<const char*>(s_rec);
 
-    // workgroup -> (tile, quadrant): every XCD works through a contiguous run of tiles, the four quadrants of a tile on four of
-    // its waves at about the same time (common.h; id = 8 (4 j + quad) + x: XCD x, j-th tile of its run)
     uint32_t tile, quad;
-    {
-        const uint32_t b = blockIdx.x, x = b & 7u, jj = b >> 3;
-        const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
-        if ((jj >> 2) >= len) return;
-        tile = start + (jj >> 2);
-        quad = jj & 3u;
-    }
+    if (!fwd_wave_item(blockIdx.x, ntiles, tile, quad)) return;
     const int lane = threadIdx.x & 63;
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
     const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);
@@ -319,13 +332,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     const char* const rec_bytes = reinterpret_cast<const char*>(s_rec);
 
     uint32_t tile, quad;
-    {
-        const uint32_t b = blockIdx.x, x = b & 7u, jj = b >> 3;
-        const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
-        if ((jj >> 2) >= len) return;
-        tile = start + (jj >> 2);
-        quad = jj & 3u;
-    }
+    if (!fwd_wave_item(blockIdx.x, ntiles, tile, quad)) return;
     const int lane = threadIdx.x & 63;
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
     const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);
