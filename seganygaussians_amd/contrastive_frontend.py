@@ -81,7 +81,7 @@ class _ContrastiveFrontEnd(torch.autograd.Function):
         ray_feat = torch.empty((S, C), device=dev, dtype=torch.float32)
         inv_len = torch.empty((N, S), device=dev, dtype=torch.float32)
         inv_norm = torch.empty((h * w,), device=dev, dtype=torch.float32)
-        norm_sum = torch.zeros((1,), device=dev, dtype=torch.float64)
+        norm_sum = torch.zeros((64 * 16,), device=dev, dtype=torch.float64)   # MI_CONTRASTIVE_NORM_SLOTS partial sums, one per 128-byte line
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = L.mi_contrastive_forward(C, h, w, rendered.data_ptr(), int(H), int(W), S, _ptr(ray_yx), N, gates_c.data_ptr(),
                                       _ptr(out), _ptr(ray_feat), _ptr(inv_len), inv_norm.data_ptr(), norm_sum.data_ptr(), stream)
@@ -89,7 +89,7 @@ class _ContrastiveFrontEnd(torch.autograd.Function):
             raise RuntimeError(_lib.last_error())
         ctx.save_for_backward(rendered, gates_c, ray_yx, out, ray_feat, inv_len, inv_norm)
         ctx.dims = (C, h, w, int(H), int(W), S, N)
-        return out, (norm_sum[0] / float(h * w)).float()
+        return out, (norm_sum.sum() / float(h * w)).float()
 
     @staticmethod
     def backward(ctx, d_out, d_norm):

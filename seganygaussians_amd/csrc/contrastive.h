@@ -9,11 +9,18 @@
 // the rays' tap gradients with float atomics (4 S C of them) and reduces the gate gradients per workgroup before its atomics.
 #pragma once
 
+#include "../../include/mi_contrastive.h"
 #include "common.h"
 
 namespace mirast {
 
 constexpr int CT_THREADS = 256;
+#ifndef CT_UNROLL
+#define CT_UNROLL 8      // channel planes whose loads are in flight per thread of the streaming passes
+#endif
+constexpr int CT_NORM_SLOTS = MI_CONTRASTIVE_NORM_SLOTS;
+constexpr int CT_MAX_CPL = 4;       // channels per lane of a ray's wave: C <= 256   // partial sums of the regulariser: same-address atomics serialise at ~22 ns each, and there are
+                                    // ~2000 workgroups at 1080p -- 64 slots, 128 bytes apart, summed by the caller
 
 // Source index and upper weight of output index `dst` for bilinear interpolation with align_corners = False
 // (ATen/native/UpSample.h area_pixel_compute_source_index: scale = in / out, src = max(0, (dst + 0.5) scale - 0.5)).
@@ -33,16 +40,20 @@ __global__ void __launch_bounds__(CT_THREADS) contrastive_fwd_kernel(
     float* __restrict__ inv_norm, double* __restrict__ norm_sum, uint32_t dense_blocks)
 {
     const size_t HW = (size_t)h * w;
-    if (blockIdx.x < dense_blocks) {
+    const uint32_t ray_blocks = gridDim.x - dense_blocks;
+    // The ray workgroups come FIRST in the grid: each is a chain of dependent gathers and wave reductions (microseconds of latency,
+    // no bandwidth) that hides under the streaming workgroups behind it -- at the end of the grid it would be the kernel's tail.
+    if (blockIdx.x >= ray_blocks) {
         // ---- dense: VEC consecutive pixels per thread
         __shared__ float s_part[CT_THREADS / 64];
-        const size_t p0 = ((size_t)blockIdx.x * CT_THREADS + threadIdx.x) * VEC;
+        const uint32_t db = blockIdx.x - ray_blocks;
+        const size_t p0 = ((size_t)db * CT_THREADS + threadIdx.x) * VEC;
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; k++) acc[k] = 0.f;
         if (p0 < HW) {
             if constexpr (VEC == 4) {
-#pragma unroll 8
+#pragma unroll CT_UNROLL
                 for (int c = 0; c < C; c++) {
                     const float4 v = *reinterpret_cast<const float4*>(rendered + (size_t)c * HW + p0);
                     acc[0] = fmaf(v.x, v.x, acc[0]);
@@ -51,7 +62,7 @@ __global__ void __launch_bounds__(CT_THREADS) contrastive_fwd_kernel(
                     acc[3] = fmaf(v.w, v.w, acc[3]);
                 }
             } else {
-#pragma unroll 8
+#pragma unroll CT_UNROLL
                 for (int c = 0; c < C; c++) {
                     const float v = rendered[(size_t)c * HW + p0];
                     acc[0] = fmaf(v, v, acc[0]);
@@ -77,38 +88,47 @@ __global__ void __launch_bounds__(CT_THREADS) contrastive_fwd_kernel(
             double t = 0.0;
 #pragma unroll
             for (int k = 0; k < CT_THREADS / 64; k++) t += (double)s_part[k];
-            atomicAdd(norm_sum, t);
+            atomicAdd(&norm_sum[(db % CT_NORM_SLOTS) * 16], t);
         }
         return;
     }
-    // ---- rays: one wave per ray
-    const int s = (int)(blockIdx.x - dense_blocks) * (CT_THREADS / 64) + (int)(threadIdx.x >> 6);
+    // ---- rays: one wave per ray; lane l holds channels l, l + 64, ... (at most CT_MAX_CPL of them) in registers
+    const int s = (int)blockIdx.x * (CT_THREADS / 64) + (int)(threadIdx.x >> 6);
     if (s >= S) return;
     const int lane = threadIdx.x & 63;
     int y0, y1, x0, x1;
     float ly, lx;
     bilinear_tap(ray_yx[2 * s], H, h, y0, y1, ly);
     bilinear_tap(ray_yx[2 * s + 1], W, w, x0, x1, lx);
-    for (int c0 = 0; c0 < C; c0 += 64) {   // (C <= 64: one trip)
-        const int c = c0 + lane;
+    float ray[CT_MAX_CPL];
+#pragma unroll
+    for (int k = 0; k < CT_MAX_CPL; k++) {
+        const int c = lane + 64 * k;
+        ray[k] = 0.f;
         if (c < C) {
             const float* f = rendered + (size_t)c * HW;
             const float top = f[(size_t)y0 * w + x0] * (1.f - lx) + f[(size_t)y0 * w + x1] * lx;
             const float bot = f[(size_t)y1 * w + x0] * (1.f - lx) + f[(size_t)y1 * w + x1] * lx;
-            ray_feat[(size_t)s * C + c] = top * (1.f - ly) + bot * ly;
+            ray[k] = top * (1.f - ly) + bot * ly;
+            ray_feat[(size_t)s * C + c] = ray[k];
         }
     }
     for (int n = 0; n < N; n++) {
-        float ss = 0.f;
-        for (int c = lane; c < C; c += 64) {
-            const float v = ray_feat[(size_t)s * C + c] * gates[(size_t)n * C + c];   // (own store above: same lane, same address)
-            ss = fmaf(v, v, ss);
+        float v[CT_MAX_CPL], ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < CT_MAX_CPL; k++) {
+            const int c = lane + 64 * k;
+            v[k] = c < C ? ray[k] * gates[(size_t)n * C + c] : 0.f;
+            ss = fmaf(v[k], v[k], ss);
         }
         ss = wave_sum(ss);
         const float il = 1.0f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize: x / max(||x||, eps), eps = 1e-12
         if (lane == 0) inv_len[(size_t)n * S + s] = il;
-        for (int c = lane; c < C; c += 64)
-            out[((size_t)n * S + s) * C + c] = ray_feat[(size_t)s * C + c] * gates[(size_t)n * C + c] * il;
+#pragma unroll
+        for (int k = 0; k < CT_MAX_CPL; k++) {
+            const int c = lane + 64 * k;
+            if (c < C) out[((size_t)n * S + s) * C + c] = v[k] * il;
+        }
     }
 }
 
@@ -124,19 +144,21 @@ __global__ void __launch_bounds__(CT_THREADS) contrastive_bwd_dense_kernel(
     if constexpr (VEC == 4) {
         float4 k = *reinterpret_cast<const float4*>(inv_norm + p0);
         k.x *= g, k.y *= g, k.z *= g, k.w *= g;
-#pragma unroll 8
+#pragma unroll CT_UNROLL
         for (int c = 0; c < C; c++) {
             const float4 v = *reinterpret_cast<const float4*>(rendered + (size_t)c * HW + p0);
             *reinterpret_cast<float4*>(dL_drendered + (size_t)c * HW + p0) = make_float4(v.x * k.x, v.y * k.y, v.z * k.z, v.w * k.w);
         }
     } else {
         const float k = inv_norm[p0] * g;
-#pragma unroll 8
+#pragma unroll CT_UNROLL
         for (int c = 0; c < C; c++) dL_drendered[(size_t)c * HW + p0] = rendered[(size_t)c * HW + p0] * k;
     }
 }
 
-// One wave per ray; a workgroup's four rays reduce their gate gradients in LDS before the atomics.
+// One wave per ray; a workgroup's four rays reduce their gate gradients in LDS before the atomics.  The gates are walked in
+// batches of CT_GB: all of a batch's loads are issued before the first reduction (one memory latency per batch, not per gate).
+constexpr int CT_GB = 5;
 __global__ void __launch_bounds__(CT_THREADS) contrastive_bwd_rays_kernel(
     int C, int h, int w, int H, int W, int S, const int* __restrict__ ray_yx, int N, const float* __restrict__ gates,
     const float* __restrict__ out, const float* __restrict__ ray_feat, const float* __restrict__ inv_len,
@@ -153,30 +175,58 @@ __global__ void __launch_bounds__(CT_THREADS) contrastive_bwd_rays_kernel(
         float ly, lx;
         bilinear_tap(ray_yx[2 * s], H, h, y0, y1, ly);
         bilinear_tap(ray_yx[2 * s + 1], W, w, x0, x1, lx);
-        for (int c0 = 0; c0 < C; c0 += 64) {
-            const int c = c0 + lane;
-            float dray = 0.f;
-            for (int n = 0; n < N; n++) {
-                // d normalize: (g - o <g, o>) / len over the channels of (n, s)
-                float dot = 0.f;
-                for (int cc = lane; cc < C; cc += 64) {
-                    const size_t i = ((size_t)n * S + s) * C + cc;
-                    dot = fmaf(dL_dout[i], out[i], dot);
-                }
-                dot = wave_sum(dot);
-                if (c < C) {
+        float ray[CT_MAX_CPL], dray[CT_MAX_CPL];
+#pragma unroll
+        for (int k = 0; k < CT_MAX_CPL; k++) {
+            const int c = lane + 64 * k;
+            ray[k] = c < C ? ray_feat[(size_t)s * C + c] : 0.f;
+            dray[k] = 0.f;
+        }
+        for (int n0 = 0; n0 < N; n0 += CT_GB) {
+            float g[CT_GB][CT_MAX_CPL], o[CT_GB][CT_MAX_CPL], gt[CT_GB][CT_MAX_CPL], il[CT_GB], dot[CT_GB];
+#pragma unroll
+            for (int b = 0; b < CT_GB; b++) {
+                const int n = min(n0 + b, N - 1);
+                il[b] = inv_len[(size_t)n * S + s];
+#pragma unroll
+                for (int k = 0; k < CT_MAX_CPL; k++) {
+                    const int c = lane + 64 * k;
                     const size_t i = ((size_t)n * S + s) * C + c;
-                    const float dsc = (dL_dout[i] - out[i] * dot) * inv_len[(size_t)n * S + s];   // d (ray * gate)
-                    dray = fmaf(dsc, gates[(size_t)n * C + c], dray);
-                    my_dg[n * C + c] = dsc * ray_feat[(size_t)s * C + c];
+                    g[b][k] = c < C ? dL_dout[i] : 0.f;
+                    o[b][k] = c < C ? out[i] : 0.f;
+                    gt[b][k] = c < C ? gates[(size_t)n * C + c] : 0.f;
                 }
             }
+#pragma unroll
+            for (int b = 0; b < CT_GB; b++) {
+                float d = 0.f;
+#pragma unroll
+                for (int k = 0; k < CT_MAX_CPL; k++) d = fmaf(g[b][k], o[b][k], d);
+                dot[b] = wave_sum(d);   // d normalize: (g - o <g, o>) / len over the channels of (n, s)
+            }
+#pragma unroll
+            for (int b = 0; b < CT_GB; b++) {
+                if (n0 + b >= N) break;
+#pragma unroll
+                for (int k = 0; k < CT_MAX_CPL; k++) {
+                    const int c = lane + 64 * k;
+                    if (c < C) {
+                        const float dsc = (g[b][k] - o[b][k] * dot[b]) * il[b];   // d (ray * gate)
+                        dray[k] = fmaf(dsc, gt[b][k], dray[k]);
+                        my_dg[(n0 + b) * C + c] = dsc * ray[k];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CT_MAX_CPL; k++) {
+            const int c = lane + 64 * k;
             if (c < C) {
-                float* g = dL_drendered + (size_t)c * HW;
-                atomicAdd(&g[(size_t)y0 * w + x0], dray * (1.f - ly) * (1.f - lx));
-                atomicAdd(&g[(size_t)y0 * w + x1], dray * (1.f - ly) * lx);
-                atomicAdd(&g[(size_t)y1 * w + x0], dray * ly * (1.f - lx));
-                atomicAdd(&g[(size_t)y1 * w + x1], dray * ly * lx);
+                float* gp = dL_drendered + (size_t)c * HW;
+                atomicAdd(&gp[(size_t)y0 * w + x0], dray[k] * (1.f - ly) * (1.f - lx));
+                atomicAdd(&gp[(size_t)y0 * w + x1], dray[k] * (1.f - ly) * lx);
+                atomicAdd(&gp[(size_t)y1 * w + x0], dray[k] * ly * (1.f - lx));
+                atomicAdd(&gp[(size_t)y1 * w + x1], dray[k] * ly * lx);
             }
         }
     }

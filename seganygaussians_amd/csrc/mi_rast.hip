@@ -758,6 +758,7 @@ int mi_contrastive_forward(int C, int h, int w, const float* rendered, int H, in
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (C < 1 || h < 1 || w < 1 || H < 1 || W < 1 || S < 0 || N < 1) return fail(MI_RAST_ERR_INVALID, "contrastive: need C, h, w, H, W, N >= 1 and S >= 0");
+    if (S > 0 && C > 64 * CT_MAX_CPL) return fail(MI_RAST_ERR_INVALID, "contrastive: at most 256 channels");
     if (!rendered || !inv_norm || !norm_sum || !gates) return fail(MI_RAST_ERR_INVALID, "contrastive: null pointer");
     if (S > 0 && (!ray_yx || !out || !ray_feat || !inv_len)) return fail(MI_RAST_ERR_INVALID, "contrastive: null ray buffers");
     const size_t HW = (size_t)h * w;
