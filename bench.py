@@ -214,15 +214,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # Settling, untimed and before the W warm-up steps: blocks of max(5, W) steps until the last five blocks all lie within
-    # 5 % of the fastest block seen, for at least 3 s and at most 20 s of wall time.  The FIRST process on a freshly
+    # Settling, untimed and before the W warm-up steps: blocks of max(5, W) steps until the blocks of the last second (at least five) all lie
+    # within 5 % of the fastest block seen, for at least 3 s and at most 20 s of wall time.  The FIRST process on a freshly
     # provisioned box runs erratically for its first seconds: measured on cfg5, blocks of ten steps took
     # 59, 72, 19, 3.5, 57, 34, 3.6, 3.5 ms/step (and a timed region right after that still caught a burst: 6.2 ms/step),
     # while the same command started again on the same box gives 19 (first step: code-object load), 3.55, 3.55 and then
     # stays there.  The kernels' own durations are normal throughout -- the host thread is what stalls (each view has one
     # host read-back, the reference API's `num_rendered`), presumably while the box's image is still paging in.  The W
     # warm-up steps alone (15 ms of work) do not cover that; waiting it out is not part of the measurement.
-    block_ms = []
+    block_ms, block_end = [], []
     nb = max(5, args.warmup)
     t_settle = time.perf_counter()
     while True:
@@ -233,7 +233,11 @@ def main():
         barrier()
         now = time.perf_counter()
         block_ms.append(round(1e3 * (now - tb) / nb, 3))
-        last = block_ms[-5:]
+        block_end.append(now)
+        # the trailing window: the last five blocks, and every block that ended within the last second (five blocks of a
+        # 3-ms step are 0.15 s -- too short to call a box settled whose stalls come seconds apart)
+        last = [m for m, te in zip(block_ms, block_end) if now - te <= 1.0]
+        last = block_ms[-5:] if len(last) < 5 else last
         settled = ((len(block_ms) >= 5 and max(last) <= 1.05 * min(block_ms) and now - t_settle >= args.settle) or now - t_settle >= 20.0
                    or args.settle <= 0)
         if dist is not None:   # every rank must run the same number of steps (each step holds a collective)
