@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Randomised parity sweep (GPU): many small random configurations against the oracle -- image sizes that are not
 multiples of 16, all channel counts, SH degrees, cov3D_precomp, mask/depth variant, random backgrounds, scale
-modifiers, dense and sparse scenes, exact depth ties.  usage: fuzz_parity.py [n_cases] [seed]"""
+modifiers, dense and sparse scenes, exact depth ties.  usage: fuzz_parity.py [n_cases] [seed] [only]
+`only` = comma-separated case numbers: only those are run, and for each the product AND the reference (oracle/_ref, when the
+variant for its channel count is built) are measured against the binary64-per-pair oracle -- who is off, and by how much."""
 import math
 import os
 import sys
@@ -15,8 +17,8 @@ from seganygaussians_amd import scenes  # noqa: E402
 from tests import helpers as hp  # noqa: E402
 
 
-def one_case(rng, k):
-    C = int(rng.choice([3, 3, 32, 32, 64]))
+def one_case(rng, k, run=True, diagnose=False):
+    C = int(rng.choice([3, 3, 32, 32, 64, 16, 48, 96, 128]))   # channel blocks: 48 = 32 + 16, 96 = 64 + 32, 128 = 64 + 64
     W, H = int(rng.integers(17, 420)), int(rng.integers(17, 300))
     P = int(rng.choice([1, 7, 300, 3000, 20000, 60000]))
     with_shs = bool(C == 3 and rng.random() < 0.5)
@@ -37,6 +39,12 @@ def one_case(rng, k):
         inp.opacities = (np.asarray(inp.opacities, np.float32) * np.float32(opa_scale)).astype(np.float32)
     desc = f"case {k}: C={C} {W}x{H} P={P} opa_scale={opa_scale} " + " ".join(f"{a}={b}" for a, b in kw.items() if a != "seed")
     one_case.desc = desc
+    if not run:   # (keeps the random stream of the later cases: draw what a run would)
+        if use_mask:
+            rng.normal(0, 1, (1, H, W))
+        return desc, -1
+    if diagnose:
+        return desc, diagnose_case(inp, C, H, W, k)
     gpu = hp.GpuRun(inp).forward()
     fwd = so.forward(inp)
     hp.compare_integer_path(gpu, fwd)
@@ -50,13 +58,38 @@ def one_case(rng, k):
     return desc, fwd.num_rendered
 
 
+def diagnose_case(inp, C, H, W, k):
+    """Product and reference against the oracle's exact-pairs mode (binary64 per-pair values and sums)."""
+    from oracle import saga_ref as sr
+    dL = scenes.make_grad_image(C, H, W, seed=k)
+    fwd = so.forward(inp)
+    exact = so.backward(inp, fwd, dL, None, exact_pairs=True)
+    gpu = hp.GpuRun(inp).forward()
+    mine = hp.error_stats(gpu.backward(dL, None), exact)
+    theirs = None
+    try:
+        ref = sr.RefRun(inp, None)
+        ref.forward()
+        theirs = hp.error_stats(hp.grads_as_dict(ref.backward(dL, None)), exact)
+    except Exception as e:  # noqa: BLE001
+        print("   (no reference run:", repr(e)[:200], ")")
+    for name, s_ in mine.items():
+        r_ = theirs.get(name) if theirs else None
+        print(f"   {name:14s} product norm {s_['norm']:.2e} rows outside {s_['row_frac']:.2e} worst {s_['row_worst']:.1f}"
+              + (f" | reference norm {r_['norm']:.2e} rows outside {r_['row_frac']:.2e} worst {r_['row_worst']:.1f}" if r_ else ""))
+    return fwd.num_rendered
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    only = {int(x) for x in sys.argv[3].split(",")} if len(sys.argv) > 3 else None
     bad = 0
     for k in range(n):
         try:
-            desc, R = one_case(rng, k)
+            desc, R = one_case(rng, k, run=only is None or k in only, diagnose=only is not None)
+            if R < 0:
+                continue
             print("ok  ", desc, "R =", R, flush=True)
         except Exception as e:  # noqa: BLE001
             bad += 1
