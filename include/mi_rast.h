@@ -62,6 +62,9 @@ extern "C" {
                                 * fails with MI_RAST_ERR_HIP if a slot the count pass reserved was not written by the emit pass */
 #define MI_RAST_TILE_FWD 32    /* 32/64-channel forward on the tile-batched bf16x3 kernel (four lockstep waves per tile, blend_fwd_x3.h)
                                   instead of the wave-per-quadrant kernel (blend_fwd_wave.h); same alpha/T/n_contrib bit for bit */
+#define MI_RAST_PREZERO_BWD 64  /* forward: leave the backward's packed gradient scratch (in the geometry buffer) zero-filled -- the wave-per-quadrant
+                                  blend kernel stores the zeros beside its own work; backward: that was done by the forward of this view and no
+                                  backward has run on its buffers since, so the fill command is skipped.  Pass it to ONE backward per forward. */
 #define MI_RAST_F32_BLEND 2    /* 32/64-channel forward on the f32 FMA-chain kernel instead of the exactly split bf16x3
                                   matrix kernel (same alpha/T/n_contrib bit for bit; images agree to a few ulp) */
 
@@ -103,6 +106,10 @@ int mi_rast_forward(
     int debug,
     int flags,                    /* MI_RAST_* bits above (0 = product default); `debug` implies MI_RAST_FULL_LISTS */
     void* features_ready_event,   /* hipEvent_t or NULL: see "List modes and the features-ready event" below */
+    float* dL_dcolor_next,        /* [P, channels] or NULL: the buffer this view's mi_rast_backward will accumulate dL_dcolor into.  When not
+                                     NULL the forward leaves it ZERO-FILLED (what torch::zeros does in CF/rasterize_points.cu:153): the
+                                     blend kernel, which is bound by VALU issue, stores the zeros beside its own work instead of a
+                                     separate 4 P channels-byte fill pass in front of the backward */
     void* stream,
     int* num_rendered /* [host] */);
 

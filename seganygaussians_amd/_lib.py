@@ -14,6 +14,7 @@ MI_GEOM_FIELDS = ["depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped
 MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed", "tile_count", "tile_cursor", "num_rendered", "blend_count", "tile_nsurv"]
 MI_BIN_FIELDS = ["entries", "scratch", "point_list", "blend_rec"]
 MI_RAST_FULL_LISTS, MI_RAST_F32_BLEND, MI_RAST_NO_CULL, MI_RAST_FAST_EXP, MI_RAST_VERIFY_LISTS, MI_RAST_TILE_FWD = 1, 2, 4, 8, 16, 32   # `flags` of mi_rast_forward (include/mi_rast.h)
+MI_RAST_PREZERO_BWD = 64   # forward + the one backward of that forward (include/mi_rast.h)
 MI_STAGES = ["preprocess", "depth_sort", "tile_scan", "emit", "tile_sort", "blend_fwd", "blend_bwd", "geom_bwd"]
 
 EXPORTS = [
@@ -54,7 +55,7 @@ def load():
     L.mi_rast_forward.restype = i
     L.mi_rast_forward.argtypes = [RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, i, i, i, i, vp, i, i,
                                   vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, i,
-                                  vp, vp, vp, vp, vp, i, i, vp, vp, C.POINTER(i)]
+                                  vp, vp, vp, vp, vp, i, i, vp, vp, vp, C.POINTER(i)]
     L.mi_rast_backward.restype = i
     L.mi_rast_backward.argtypes = [i, i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]

@@ -108,7 +108,7 @@ constexpr int BIN_MAX_TILES = 26 * 1024 - 64;  // per launch of the count / emit
                                                // arrays must fit in 160 KB; larger images are walked in bands of tile rows
 constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
 
-__global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_total,
+__global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
                                                            uint32_t big_threshold, int big_limit,
                                                            uint32_t* __restrict__ big_list, int* __restrict__ host_out = nullptr,
@@ -117,7 +117,9 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uin
     // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
     // one workgroup scan joins the pieces, and the ranges leave coalesced again.  Items below big_limit with more
     // than big_threshold entries are appended to big_list (count in big_list[0], order arbitrary).
-    extern __shared__ uint32_t s_val[];  // [ntiles + 1]
+    // More than BIN_MAX_TILES_TOTAL items (images beyond 10 Mpx) are walked in segments of that many, one after the other, the
+    // running total carried along: ONE pass of the loop below for every image up to 4096 x 2544.
+    extern __shared__ uint32_t s_val[];  // [min(ntiles_all, BIN_MAX_TILES_TOTAL) + 1]
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_maxcount;
     __shared__ uint32_t s_nbig;
@@ -126,49 +128,55 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, const uin
         s_maxcount = 0;
         s_nbig = 0;
     }
-    for (int i = tid; i < ntiles; i += 1024) s_val[i] = tile_total[i];
-    __syncthreads();
-    const int per = (ntiles + 1023) / 1024;
-    const int i0 = min(ntiles, tid * per), i1 = min(ntiles, i0 + per);
-    uint32_t sum = 0, mx = 0;
-    for (int i = i0; i < i1; i++) {
-        const uint32_t c = s_val[i];
-        s_val[i] = sum;  // exclusive prefix inside the piece
-        sum += c;
-        mx = max(mx, c);
-    }
-    const uint32_t incl = wave_inclusive_scan(sum, lane);
-    if (lane == 63) s_wave[wave] = incl;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-    __syncthreads();
-    if (lane == 0 && mx) atomicMax(&s_maxcount, mx);
-    uint32_t woff = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) {
-        const uint32_t c = s_wave[w];
-        woff += w < wave ? c : 0u;
-        total += c;
-    }
-    const uint32_t piece_base = woff + incl - sum;
-    for (int i = i0; i < i1; i++) s_val[i] += piece_base;
-    if (tid == 0) s_val[ntiles] = total;
-    __syncthreads();
-    for (int i = tid; i < ntiles; i += 1024) {
-        const uint32_t lo = s_val[i], hi = s_val[i + 1];
-        ranges[i] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);
-        if (zero_a != nullptr) {   // per-tile words a later kernel accumulates into with atomicMax (blend_fwd_wave.h)
-            zero_a[i] = 0u;
-            zero_b[i] = 0u;
+    uint32_t carry = 0;   // entries in front of the segment (the same in every thread)
+    for (int seg0 = 0; seg0 < ntiles_all; seg0 += BIN_MAX_TILES_TOTAL) {
+        const int ntiles = min(BIN_MAX_TILES_TOTAL, ntiles_all - seg0);
+        for (int i = tid; i < ntiles; i += 1024) s_val[i] = tile_total[seg0 + i];
+        __syncthreads();
+        const int per = (ntiles + 1023) / 1024;
+        const int i0 = min(ntiles, tid * per), i1 = min(ntiles, i0 + per);
+        uint32_t sum = 0, mx = 0;
+        for (int i = i0; i < i1; i++) {
+            const uint32_t c = s_val[i];
+            s_val[i] = sum;  // exclusive prefix inside the piece
+            sum += c;
+            mx = max(mx, c);
         }
-        if (big_list != nullptr && i < big_limit && hi - lo > big_threshold) big_list[1 + atomicAdd(&s_nbig, 1u)] = (uint32_t)i;
+        const uint32_t incl = wave_inclusive_scan(sum, lane);
+        if (lane == 63) s_wave[wave] = incl;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        __syncthreads();
+        if (lane == 0 && mx) atomicMax(&s_maxcount, mx);
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t c = s_wave[w];
+            woff += w < wave ? c : 0u;
+            total += c;
+        }
+        const uint32_t piece_base = carry + woff + incl - sum;
+        for (int i = i0; i < i1; i++) s_val[i] += piece_base;
+        if (tid == 0) s_val[ntiles] = carry + total;
+        __syncthreads();
+        for (int i = tid; i < ntiles; i += 1024) {
+            const uint32_t lo = s_val[i], hi = s_val[i + 1];
+            ranges[seg0 + i] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+            if (zero_a != nullptr) {   // per-tile words a later kernel accumulates into with atomicMax (blend_fwd_wave.h)
+                zero_a[seg0 + i] = 0u;
+                zero_b[seg0 + i] = 0u;
+            }
+            if (big_list != nullptr && seg0 + i < big_limit && hi - lo > big_threshold)
+                big_list[1 + atomicAdd(&s_nbig, 1u)] = (uint32_t)(seg0 + i);
+        }
+        carry += total;
+        __syncthreads();   // s_val / s_wave are rewritten by the next segment
     }
-    __syncthreads();
     if (tid == 0) {
-        num_rendered[0] = (int)total;       // R (the host already has it from the preprocess pass; kept for checks)
+        num_rendered[0] = (int)carry;       // R (the host already has it from the preprocess pass; kept for checks)
         num_rendered[1] = (int)s_maxcount;  // longest list
         if (host_out != nullptr) {          // the same two words straight into the host's pinned buffer (no copy command)
-            host_out[0] = (int)total;
+            host_out[0] = (int)carry;
             host_out[1] = (int)s_maxcount;
         }
         if (big_list != nullptr) big_list[0] = s_nbig;

@@ -41,6 +41,24 @@ __device__ __forceinline__ bool fwd_wave_item(uint32_t b, uint32_t ntiles, uint3
 #endif
 }
 
+// Zero-fill riding on the forward blend (include/mi_rast.h: dL_dcolor_next, MI_RAST_PREZERO_BWD).  The backward accumulates
+// dL_dcolor and its packed per-Gaussian fields with atomics, so both must be zero when it starts: 160 MB of fill per cfg3 view
+// (two fill kernels, 25 us of a 1.23-ms step) that this kernel -- bound by VALU issue, a fifth of the HBM rate in use -- stores on
+// the side: workgroup b of nb writes the 1-KB pieces b, b + nb, ... before it starts on its quadrant (four or five
+// dwordx4 stores per wave on cfg3).
+struct FwdZeroFill {
+    float4* a;      // region 1 (dL_dcolor_next) ...
+    uint32_t na;    // ... in 16-byte units
+    float4* b;      // region 2 (the geometry buffer's bwd_pack + work-queue counters)
+    uint32_t nb;
+};
+__device__ __forceinline__ void fwd_zero_fill(const FwdZeroFill& z, uint32_t wg, uint32_t nwg, int lane)
+{
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t i = wg * 64u + (uint32_t)lane; i < z.na; i += nwg * 64u) z.a[i] = zero;
+    for (uint32_t i = wg * 64u + (uint32_t)lane; i < z.nb; i += nwg * 64u) z.b[i] = zero;
+}
+
 #ifndef MI_FWD_WAVES32
 #define MI_FWD_WAVES32 4   // waves per SIMD the 32-channel instance is compiled for (register budget 512 / waves)
 #endif
@@ -54,7 +72,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed /* zeroed: receives atomicMax */,
     uint32_t* __restrict__ tile_nsurv /* zeroed: receives atomicMax */, const float* __restrict__ bg_color,
-    float* __restrict__ out_color, int cstride_arg /* STRIDED: floats between feature rows (blend_fwd.h) */)
+    float* __restrict__ out_color, int cstride_arg /* STRIDED: floats between feature rows (blend_fwd.h) */, FwdZeroFill zfill)
 {
     static_assert(C == 32 || C == 64, "32-channel accumulator blocks");
     constexpr int F4 = C / 4, NCB = C / 32, XROW = 6 * C, PLANE = 2 * C;  // float4s per row; channel blocks; row / plane bytes
@@ -69,6 +87,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
     char* const featb = reinterpret_cast<char*>(s_feat4);
     const char* const rec_bytes = reinterpret_cast<const char*>(s_rec);
 
+    fwd_zero_fill(zfill, blockIdx.x, gridDim.x, (int)(threadIdx.x & 63));   // (every workgroup, also those without an item)
     uint32_t tile, quad;
     if (!fwd_wave_item(blockIdx.x, ntiles, tile, quad)) return;
     const int lane = threadIdx.x & 63;
@@ -322,7 +341,8 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features /* [P,3] */,
     const float* __restrict__ mask, const float* __restrict__ depths, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed, uint32_t* __restrict__ tile_nsurv,
-    const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_mask, float* __restrict__ out_depth)
+    const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_mask, float* __restrict__ out_depth,
+    FwdZeroFill zfill)
 {
     constexpr int C = 3, CE = C + EXTRA, QCAP = 128, FROW = 8;
     __shared__ XRec s_rec[XG];
@@ -331,6 +351,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     __shared__ uint32_t s_j[XG];
     const char* const rec_bytes = reinterpret_cast<const char*>(s_rec);
 
+    fwd_zero_fill(zfill, blockIdx.x, gridDim.x, (int)(threadIdx.x & 63));   // (every workgroup, also those without an item)
     uint32_t tile, quad;
     if (!fwd_wave_item(blockIdx.x, ntiles, tile, quad)) return;
     const int lane = threadIdx.x & 63;

@@ -328,6 +328,12 @@ std::mutex g_attr_mutex;
 // kernels (CF/cuda_rasterizer/config_contrastive_f.h:15).
 constexpr int MAX_CHANNELS = 256;
 constexpr int MAX_CHANNEL_BLOCKS = MAX_CHANNELS / 16;
+// bytes of the geometry buffer's bwd_pack field: the packed per-Gaussian field gradients + the backward's work-queue counters (one set
+// of eight per channel block); zero when mi_rast_backward starts its blend pass
+inline size_t bwd_pack_bytes(int P)
+{
+    return (size_t)(P > 0 ? P : 1) * 8 * sizeof(float) + MAX_CHANNEL_BLOCKS * 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t);
+}
 bool channels_supported(int c) { return c == 3 || (c >= 16 && c <= MAX_CHANNELS && c % 16 == 0); }
 // next block of a feature with `rem` channels left
 int channel_block(int rem) { return rem >= 64 ? 64 : (rem >= 32 ? 32 : 16); }
@@ -362,8 +368,6 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (P >= (1 << RANK_BITS)) return fail(MI_RAST_ERR_INVALID, "more than 2^28 Gaussians");
     if (vp.grid_x > 1023u || vp.grid_y > 2047u)
         return fail(MI_RAST_ERR_INVALID, "image too large: more than 1023 tiles across or 2047 tiles down");
-    if (ntiles > BIN_MAX_TILES_TOTAL)
-        return fail(MI_RAST_ERR_INVALID, "image too large: more than 40896 tiles (e.g. 4096 x 2544 px at 16-px tiles)");
     // images with more tiles than one launch of the count / emit passes has LDS counters for are walked in bands of tile rows
     // (grid_x + 2: the count passes keep band_rows (+ 1) rows of an odd stride >= grid_x + 1 in the same LDS budget)
     const uint32_t band_rows = std::min<uint32_t>(vp.grid_y, std::max<uint32_t>(1u, (uint32_t)BIN_MAX_TILES / (vp.grid_x + 2u) - 1u));
@@ -462,7 +466,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         }
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)ntiles + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
                            img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr,
                            g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv);
     }
@@ -595,14 +599,16 @@ void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs
 // One wave per (tile, quadrant): 32 x the longest XCD run of tiles workgroups (blend_fwd_wave.h).
 template <int C>
 void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const float* features,
-                           const float* bg, float* out_color, bool xexp, int cstride)
+                           const float* bg, float* out_color, bool xexp, int cstride, FwdZeroFill& zfill)
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
     const uint32_t grid = 32u * ((nt + 7u) >> 3);
+    const FwdZeroFill zf = zfill;
+    zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};   // taken: the launches of further channel blocks fill nothing
 #define FW_LAUNCH(XE, ST)                                                                                                     \
     hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XE, ST>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec,            \
                        img.blend_count, vp.W, vp.H, vp.grid_x, nt, features, img.final_T, img.n_contrib, img.tile_consumed,       \
-                       img.tile_nsurv, bg, out_color, cstride)
+                       img.tile_nsurv, bg, out_color, cstride, zf)
     if (cstride == C) {
         if (xexp) FW_LAUNCH(true, false);
         else FW_LAUNCH(false, false);
@@ -616,18 +622,20 @@ void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPt
 template <int EXTRA>
 void launch_blend_fwd_wave_rgb(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const GeomPtrs& geom,
                                const float* features, const float* mask, const float* bg, float* out_color, float* out_mask,
-                               float* out_depth, bool xexp)
+                               float* out_depth, bool xexp, FwdZeroFill& zfill)
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
     const uint32_t grid = 32u * ((nt + 7u) >> 3);
+    const FwdZeroFill zf = zfill;
+    zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};
     if (xexp)
         hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, true>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec, img.blend_count,
                            vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,
-                           img.tile_nsurv, bg, out_color, out_mask, out_depth);
+                           img.tile_nsurv, bg, out_color, out_mask, out_depth, zf);
     else
         hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, false>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec, img.blend_count,
                            vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,
-                           img.tile_nsurv, bg, out_color, out_mask, out_depth);
+                           img.tile_nsurv, bg, out_color, out_mask, out_depth, zf);
 }
 
 template <int C, bool MASKGRAD>
@@ -901,7 +909,7 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_INDEX_REC] = c.take(p * sizeof(BlendRec));
     off[MI_GEOM_SORTED_IDX] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_SORT_TEMP] = c.take(depth_sort_temp_bytes(P) + 16);
-    off[MI_GEOM_BWD_PACK] = c.take(p * 8 * sizeof(float) + MAX_CHANNEL_BLOCKS * 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t));  // + the backward's work-queue counters, one set per channel block
+    off[MI_GEOM_BWD_PACK] = c.take(bwd_pack_bytes((int)p));  // + the backward's work-queue counters, one set per channel block
     off[MI_GEOM_RANK_REC] = c.take(p * sizeof(BlendRec));
     return c.off;
 }
@@ -964,7 +972,7 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
                     float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                     const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
                     const float* mask, float* out_color, float* out_mask, float* out_depth, int* radii, int debug,
-                    int flags, void* features_ready_event, void* stream_, int* num_rendered)
+                    int flags, void* features_ready_event, float* dL_dcolor_next, void* stream_, int* num_rendered)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (num_rendered) *num_rendered = 0;
@@ -995,12 +1003,32 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
     }
     {
         StageTimer t(stream, MI_STAGE_BLEND_FWD);
+        // zero-fill for the backward of this view (mi_rast.h: dL_dcolor_next, MI_RAST_PREZERO_BWD): stored by the first wave-per-quadrant
+        // blend launch beside its own work (blend_fwd_wave.h); tails that are not whole 16-byte units, and everything when another
+        // kernel blends, by fill commands
+        FwdZeroFill zfill{nullptr, 0u, nullptr, 0u};
+        {
+            auto region = [&](float* ptr, size_t bytes, float4*& p, uint32_t& n16) -> int {
+                if (ptr == nullptr || bytes == 0) return MI_RAST_OK;
+                if ((reinterpret_cast<uintptr_t>(ptr) & 15u) != 0 || (bytes >> 4) > 0xFFFFFFFFull) {
+                    HIP_TRY(hipMemsetAsync(ptr, 0, bytes, stream));
+                    return MI_RAST_OK;
+                }
+                p = reinterpret_cast<float4*>(ptr);
+                n16 = (uint32_t)(bytes >> 4);
+                if (bytes & 15u) HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(ptr) + (bytes & ~(size_t)15), 0, bytes & 15u, stream));
+                return MI_RAST_OK;
+            };
+            if ((rc = region(dL_dcolor_next, (size_t)P * channels * sizeof(float), zfill.a, zfill.na))) return rc;
+            if (flags & MI_RAST_PREZERO_BWD)
+                if ((rc = region(geom.bwd_pack, bwd_pack_bytes(P), zfill.b, zfill.nb))) return rc;
+        }
         const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;
         const bool tile_fwd_rgb = (flags & MI_RAST_TILE_FWD) != 0;   // the tile-batched kernels instead of the wave-per-quadrant ones
         if (mask && tile_fwd_rgb) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
-        else if (mask) launch_blend_fwd_wave_rgb<2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
+        else if (mask) launch_blend_fwd_wave_rgb<2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp, zfill);
         else if (channels == 3 && tile_fwd_rgb) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
-        else if (channels == 3) launch_blend_fwd_wave_rgb<0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
+        else if (channels == 3) launch_blend_fwd_wave_rgb<0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp, zfill);
         else {
             // feature channels in blocks of 64 / 32 / 16 (one launch per block; see channels_supported)
             const size_t HW = (size_t)width * height;
@@ -1014,17 +1042,20 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
                 if (cb == 64) {
                     if (f32_blend) launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
                     else if (tile_fwd) launch_blend_fwd_x3<64>(vp, stream, img, bin, f, bgp, out, xexp, channels);
-                    else launch_blend_fwd_wave<64>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                    else launch_blend_fwd_wave<64>(vp, stream, img, bin, f, bgp, out, xexp, channels, zfill);
                 } else if (cb == 32) {
                     if (f32_blend) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
                     else if (tile_fwd) launch_blend_fwd_x3<32>(vp, stream, img, bin, f, bgp, out, xexp, channels);
-                    else launch_blend_fwd_wave<32>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                    else launch_blend_fwd_wave<32>(vp, stream, img, bin, f, bgp, out, xexp, channels, zfill);
                 } else {
                     launch_blend_fwd<16, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
                 }
                 c0 += cb;
             }
         }
+        // no wave-per-quadrant launch took the fill (tile-batched / f32 / 16-channel kernels): fill commands
+        if (zfill.na) HIP_TRY(hipMemsetAsync(zfill.a, 0, (size_t)zfill.na << 4, stream));
+        if (zfill.nb) HIP_TRY(hipMemsetAsync(zfill.b, 0, (size_t)zfill.nb << 4, stream));
     }
     STAGE_CHECK("render");
     return MI_RAST_OK;
@@ -1056,7 +1087,8 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     const float* color_ptr = (colors_precomp != nullptr) ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:389
     {
         StageTimer t(stream, MI_STAGE_BLEND_BWD);
-        HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, (size_t)P * 8 * sizeof(float) + MAX_CHANNEL_BLOCKS * 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t), stream));
+        // (MI_RAST_PREZERO_BWD: the forward of this view left the block zeroed, and no backward has run on it since)
+        if (!(flags & MI_RAST_PREZERO_BWD)) HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, bwd_pack_bytes(P), stream));
         uint32_t* queue_ctr = reinterpret_cast<uint32_t*>(geom.bwd_pack + (size_t)P * 8);   // one set of eight counters per channel block
         const float* bg_blk = background;
         const float* colors_blk = color_ptr;

@@ -17,6 +17,7 @@ CPU fallback: missing library or non-GPU tensors raise.
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 import threading
 from typing import NamedTuple
@@ -129,8 +130,14 @@ def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, 
 
 def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, colors, opacity, mask, scales,
                                rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
-                               image_height, image_width, sh, degree, campos, prefiltered, debug):
-    """RasterizeGaussiansCUDA (CF/rasterize_points.cu:35-115; DEPTH/rasterize_points.cu:35-130)."""
+                               image_height, image_width, sh, degree, campos, prefiltered, debug, prezero=False):
+    """RasterizeGaussiansCUDA (CF/rasterize_points.cu:35-115; DEPTH/rasterize_points.cu:35-130).
+
+    prezero (a backward will follow: the autograd Functions set it when an input requires grad): the forward also leaves the
+    backward's accumulators zero-filled -- a (P, channels) dL_dcolors tensor allocated here and the packed field gradients
+    inside the geometry buffer -- stored by the blend kernel beside its own work (include/mi_rast.h: dL_dcolor_next,
+    MI_RAST_PREZERO_BWD) instead of by two fill passes in front of the backward.  The tensor is left on the returned geometry
+    buffer as `.mi_prezero`; hand it to ONE rasterize_gaussians_backward_native call (`prezeroed=`)."""
     ready = _opts.features_ready          # one-shot: consumed by THIS forward whatever happens below (P == 0, an exception)
     _opts.features_ready = None
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
@@ -153,6 +160,7 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
                                    viewmatrix, projmatrix, campos, mask)]
         bg_c, m3_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, vm_c, pm_c, cp_c, mk_c = t
         n = C.c_int(0)
+        grad_colors = torch.empty((P, channels), dtype=torch.float32, device=dev) if prezero else None
         if with_mask_depth and (mk_c is None or mk_c.numel() != P or not mk_c.is_cuda or mk_c.dtype != torch.float32):
             # the DEPTH package always passes a mask (DEPTH/.../__init__.py:323); without one out_mask / out_depth
             # would be left unwritten
@@ -168,11 +176,14 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
                 int(bool(prefiltered)), _dev_ptr(mk_c, "mask", dev) if with_mask_depth else None,
                 out_color.data_ptr(), out_mask.data_ptr() if with_mask_depth else None,
                 out_depth.data_ptr() if with_mask_depth else None, radii.data_ptr(), int(bool(debug)),
-                int(_opts.flags), None if ready is None else C.c_void_p(ready.cuda_event), _stream_ptr(dev),
-                C.byref(n))
+                int(_opts.flags) | (_lib.MI_RAST_PREZERO_BWD if prezero else 0),
+                None if ready is None else C.c_void_p(ready.cuda_event),
+                None if grad_colors is None else grad_colors.data_ptr(), _stream_ptr(dev), C.byref(n))
         del ready
         geom.tensor.mi_flags = int(_opts.flags)   # the backward re-takes the forward's decisions: it needs the same flags
         _check(rc)
+        if grad_colors is not None:
+            geom.tensor.mi_prezero = grad_colors
         rendered = n.value
     else:
         out_color = torch.zeros((channels, H, W), dtype=torch.float32, device=dev)
@@ -201,8 +212,11 @@ def _flags_of(geomBuffer, flags):
 def rasterize_gaussians_backward_native(channels, with_mask_depth, background, means3D, radii, colors, scales,
                                         rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
                                         tan_fovy, dL_dout_color, dL_dout_mask, sh, degree, campos, geomBuffer, R,
-                                        binningBuffer, imageBuffer, debug, flags=None):
-    """RasterizeGaussiansBackwardCUDA (CF/rasterize_points.cu:117-196; DEPTH/rasterize_points.cu)."""
+                                        binningBuffer, imageBuffer, debug, flags=None, prezeroed=None):
+    """RasterizeGaussiansBackwardCUDA (CF/rasterize_points.cu:117-196; DEPTH/rasterize_points.cu).
+
+    prezeroed: the zero-filled (P, channels) tensor the forward of THESE buffers produced with prezero=True, not used by any
+    backward before: it becomes dL_dcolors, and the fill of the packed field gradients is skipped as well."""
     L = _lib.load()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -230,7 +244,9 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
     flat = torch.empty(sum(sizes), **o)
     if debug:
         flat.fill_(float("nan"))
-    g = {"dL_dcolors": torch.zeros((P, channels), **o), "dL_dsh": torch.zeros((P, M, 3), **o)}
+    if prezeroed is not None and (tuple(prezeroed.shape) != (P, channels) or prezeroed.device != dev or debug):
+        prezeroed = None
+    g = {"dL_dcolors": prezeroed if prezeroed is not None else torch.zeros((P, channels), **o), "dL_dsh": torch.zeros((P, M, 3), **o)}
     off = 0
     for (name, shp), n in zip(shapes, sizes):
         cnt = 1
@@ -259,7 +275,8 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
                 dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
                 dL_dmask.data_ptr() if with_mask_depth else None, dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M > 0 else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(),
-                int(bool(debug)), int(_flags_of(geomBuffer, flags)), _stream_ptr(dev))
+                int(bool(debug)), int(_flags_of(geomBuffer, flags)) | (_lib.MI_RAST_PREZERO_BWD if prezeroed is not None else 0),
+                _stream_ptr(dev))
         _check(rc)
     if with_mask_depth:
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmask, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
@@ -353,10 +370,13 @@ def _make_plain(channels):
                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                     rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
 
+            # a backward will follow: its accumulators are zero-filled by the forward's blend kernel (rasterize_gaussians_native)
+            prezero = bool(any(ctx.needs_input_grad)) and not rs.debug and not os.environ.get("MI_RAST_NO_PREZERO")   # (env: A/B aid)
+
             def call():
                 (bg, m3, col, op, sc, rot, smod, cov, vm, pm, tx, ty, ih, iw, sh_, deg, cp, pre, dbg) = args
                 return rasterize_gaussians_native(channels, False, bg, m3, col, op, None, sc, rot, smod, cov, vm, pm,
-                                                  tx, ty, ih, iw, sh_, deg, cp, pre, dbg)
+                                                  tx, ty, ih, iw, sh_, deg, cp, pre, dbg, prezero=prezero)
 
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)  # Copy them before they can be corrupted
@@ -371,6 +391,7 @@ def _make_plain(channels):
             ctx.raster_settings = rs
             ctx.num_rendered = num_rendered
             ctx.mi_flags = getattr(geomBuffer, "mi_flags", 0)
+            ctx.mi_prezero = geomBuffer.__dict__.pop("mi_prezero", None)   # one-shot: the first backward takes it
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
@@ -391,11 +412,13 @@ def _make_plain(channels):
                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
                     geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug)
 
+            prezeroed, ctx.mi_prezero = ctx.mi_prezero, None   # (a second backward through a retained graph fills for itself)
+
             def call():
                 (bg, m3, rad, col, sc, rot, smod, cov, vm, pm, tx, ty, gout, sh_, deg, cp, gb, nr, bb, ib, dbg) = args
                 return rasterize_gaussians_backward_native(channels, False, bg, m3, rad, col, sc, rot, smod, cov, vm,
                                                            pm, tx, ty, gout, None, sh_, deg, cp, gb, nr, bb, ib, dbg,
-                                                           flags=ctx.mi_flags)
+                                                           flags=ctx.mi_flags, prezeroed=prezeroed)
 
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)

@@ -96,7 +96,8 @@ class GpuRun:
         self.mask = t(inp.mask)
         self.with_mask = inp.mask is not None
 
-    def forward(self, debug=False, full_lists=True, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None):
+    def forward(self, debug=False, full_lists=True, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None,
+                prezero=False):
         """full_lists=True materialises the reference's point_list / full-list positions (what the bit-exact
         comparisons with the oracle read); False is the product default ("lean" lists, include/mi_rast.h)."""
         i = self.inp
@@ -105,7 +106,7 @@ class GpuRun:
             res = self.R.rasterize_gaussians_native(
                 i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
                 self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,
-                i.image_width, self.shs, i.sh_degree, self.campos, i.prefiltered, debug)
+                i.image_width, self.shs, i.sh_degree, self.campos, i.prefiltered, debug, prezero=prezero)
         self.full_lists = bool(full_lists or debug)
         if self.with_mask:
             (self.num_rendered, self.color, self.out_mask, self.out_depth, self.radii, self.geom, self.binning,
@@ -115,7 +116,7 @@ class GpuRun:
             self.out_mask = self.out_depth = None
         return self
 
-    def backward(self, dL_dout_color, dL_dout_mask=None, debug=False):
+    def backward(self, dL_dout_color, dL_dout_mask=None, debug=False, prezeroed=None):
         i, torch = self.inp, self.torch
         g = torch.as_tensor(np.ascontiguousarray(dL_dout_color, np.float32)).to(self.dev)
         gm = None
@@ -126,7 +127,7 @@ class GpuRun:
         res = self.R.rasterize_gaussians_backward_native(
             i.channels, self.with_mask, self.bg, self.means3D, self.radii, self.colors, self.scales, self.rots,
             i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, g, gm, self.shs, i.sh_degree,
-            self.campos, self.geom, self.num_rendered, self.binning, self.img, debug)
+            self.campos, self.geom, self.num_rendered, self.binning, self.img, debug, prezeroed=prezeroed)
         names = (["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmask", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
                   "dL_dscales", "dL_drotations"] if self.with_mask else
                  ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",

@@ -59,6 +59,30 @@ def test_autograd_through_dropin(pkg, C):
     assert torch.equal(c2, color.detach())
 
 
+def test_second_backward_through_a_retained_graph():
+    """The forward hands its pre-zeroed accumulators (rasterizer.py: prezero) to ONE backward; a second backward through a
+    retained graph must fill its own and give the same gradients."""
+    import diff_gaussian_rasterization_contrastive_f as mod
+    dev = torch.device("cuda:0")
+    inp = hp.make_inputs(5000, 160, 112, 32, seed=33, camera="orbit")
+    means3D, feats = _leaf(inp.means3D, dev), _leaf(inp.colors_precomp, dev)
+    opac, scales, rots = _leaf(inp.opacities, dev), _leaf(inp.scales, dev), _leaf(inp.rotations, dev)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    rast = mod.GaussianRasterizer(raster_settings=_settings(mod, inp, dev))
+    color, _ = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=feats, opacities=opac, scales=scales,
+                    rotations=rots, cov3D_precomp=None)
+    dL = torch.as_tensor(scenes.make_grad_image(32, 112, 160, seed=6)).to(dev)
+    color.backward(dL, retain_graph=True)
+    first = {k: v.grad.clone() for k, v in (("feats", feats), ("means3D", means3D), ("opac", opac))}
+    color.backward(dL)
+    for k, v in (("feats", feats), ("means3D", means3D), ("opac", opac)):
+        hp.assert_close(k + " (second backward)", (v.grad - first[k]).cpu().numpy(), first[k].cpu().numpy(), rtol=2e-4,
+                        flip_frac=hp.GRAD_FLIP_FRAC)
+    bwd = so.backward(inp, so.forward(inp), dL.cpu().numpy())
+    hp.assert_close("colors_precomp", first["feats"].cpu().numpy(), np.asarray(bwd.dL_dcolors).reshape(first["feats"].shape),
+                    flip_frac=hp.GRAD_FLIP_FRAC)
+
+
 def test_depth_package_and_forward_mask():
     import diff_gaussian_rasterization_depth as mod
     dev = torch.device("cuda:0")

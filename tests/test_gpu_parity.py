@@ -335,6 +335,46 @@ def test_cull_is_exactly_conservative(case):
         hp.assert_close(k + " (cull off vs on)", g_off[k], want, rtol=2e-4, flip_frac=max(hp.GRAD_FLIP_FRAC, 1.5 / max(1, want.size)))
 
 
+@pytest.mark.parametrize("C,kw", [(3, {}), (3, {"use_mask": True}), (32, {}), (48, {}), (64, {}), (16, {}), (32, {"tile_fwd": True})])
+def test_forward_prefills_the_backward_accumulators(C, kw):
+    """include/mi_rast.h dL_dcolor_next / MI_RAST_PREZERO_BWD: the forward's blend kernel leaves the backward's accumulators --
+    the (P, channels) dL_dcolor buffer and the packed field gradients + work-queue counters in the geometry buffer -- zero-filled
+    (what torch::zeros does in CF/rasterize_points.cu:153-159), and the backward then skips its fills.  Checked with NaN /
+    0xFF left in the allocator's free blocks, for the wave-per-quadrant kernels (RGB, RGB + mask + depth, 32, 64, 48 = 32 + 16:
+    the first block's launch takes the fill), for kernels that do not take it (16 channels; the tile-batched forward: fill
+    commands), and with an odd P (the (P, 3) buffer is not a whole number of 16-byte units).  Gradients equal those of a plain run."""
+    import torch
+    from seganygaussians_amd import _lib
+    kw = dict(kw)
+    tile_fwd = kw.pop("tile_fwd", None)
+    P, W, H = 7001, 200, 136
+    inp = hp.make_inputs(P, W, H, C, seed=41, camera="orbit", bg="random", **kw)
+    dL = scenes.make_grad_image(C, H, W, seed=5)
+    dLm = None if inp.mask is None else (np.random.default_rng(9).normal(0, 1, (1, H, W)) / (W * H)).astype(np.float32)
+    plain = hp.GpuRun(inp).forward(full_lists=False, tile_fwd=tile_fwd)
+    g_plain = plain.backward(dL, dLm)
+    geom_bytes, off = _lib.geometry_layout(P)
+    dev = plain.dev
+    junk = [torch.full((P, C), float("nan"), device=dev), torch.full((int(plain.geom.numel()),), 0xFF, dtype=torch.uint8, device=dev)]
+    del plain, junk
+    run = hp.GpuRun(inp).forward(full_lists=False, tile_fwd=tile_fwd, prezero=True)
+    pre = run.geom.mi_prezero
+    torch.cuda.synchronize()
+    assert tuple(pre.shape) == (P, C) and pre.dtype == torch.float32
+    assert int(torch.count_nonzero(pre.view(torch.int32))) == 0, "dL_dcolor_next not zero-filled"
+    pack = run._view(run.geom, off["bwd_pack"], 8 * P + 16 * 8 * 16, np.uint32)
+    assert not pack.any(), "bwd_pack / queue counters not zero-filled"
+    g = run.backward(dL, dLm, prezeroed=pre)
+    for k, want in g_plain.items():
+        hp.assert_close(k + " (prezeroed vs plain)", g[k], want, rtol=2e-4, flip_frac=max(hp.GRAD_FLIP_FRAC, 1.5 / max(1, want.size)))
+    hidden = run.radii.cpu().numpy() == 0
+    assert hidden.any() and not g["dL_dcolors"][hidden].any() and np.isfinite(g["dL_dcolors"]).all()
+    # a second backward on the same buffers must fill for itself (the autograd Functions hand the tensor over once)
+    g2 = run.backward(dL, dLm)
+    for k, want in g_plain.items():
+        hp.assert_close(k + " (second backward)", g2[k], want, rtol=2e-4, flip_frac=max(hp.GRAD_FLIP_FRAC, 1.5 / max(1, want.size)))
+
+
 def test_4k_image_walked_in_bands():
     """3840 x 2160 = 32 400 tiles: more than one launch of the count / emit passes has LDS counters for (29 632), so the
     host walks the image in two bands of tile rows.  Same bit-exact integer path, same tolerances."""
@@ -343,13 +383,23 @@ def test_4k_image_walked_in_bands():
     assert fwd.num_rendered > 1_000_000
     ranges = gpu.img_fields()["ranges"].reshape(-1, 2).astype(np.int64)
     assert len(ranges) == 240 * 135 and (ranges[30000:, 1] - ranges[30000:, 0]).sum() > 0, "the second band must hold overlaps"
-    # beyond 40 896 tiles the single-workgroup range scan runs out of LDS: refused, not mis-rendered
-    import torch
+
+
+def test_5k_image_range_scan_in_segments():
+    """5120 x 2880 = 57 600 tiles: more than the range scan's workgroup holds in LDS (40 896), so tile_ranges_kernel walks the
+    tile totals in two segments with the running total carried over (and the count / emit passes walk three bands).  Same
+    bit-exact integer path, same tolerances; the reference has no image-size limit (rasterizer_impl.cu:198-336)."""
+    inp = hp.make_inputs(30_000, 5120, 2880, 3, seed=22, focal=4000.0, log_scale=math.log(0.06), log_scale_std=0.7, bg="random")
+    rep, gpu, fwd = _fwd_bwd(inp)
+    assert fwd.num_rendered > 1_000_000
+    ranges = gpu.img_fields()["ranges"].reshape(-1, 2).astype(np.int64)
+    assert len(ranges) == 320 * 180 and (ranges[40896:, 1] - ranges[40896:, 0]).sum() > 0, "the second segment must hold overlaps"
+    # what remains refused: more than 1023 tiles across or 2047 down (the span records pack tile coordinates in 10 + 11 bits)
     from seganygaussians_amd import rasterizer as R
     g = hp.GpuRun(hp.make_inputs(100, 64, 64, 3, seed=1))
     with pytest.raises(RuntimeError, match="image too large"):
         R.rasterize_gaussians_native(3, False, g.bg, g.means3D, g.colors, g.opac, None, g.scales, g.rots, 1.0, g.cov, g.view,
-                                     g.proj, 1.0, 1.0, 2720, 4096, g.shs, 0, g.campos, False, False)
+                                     g.proj, 1.0, 1.0, 16, 16400, g.shs, 0, g.campos, False, False)
 
 
 def test_lean_expf_is_the_device_expf(tmp_path):
