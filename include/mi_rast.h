@@ -109,7 +109,8 @@ int mi_rast_forward(
     float* dL_dcolor_next,        /* [P, channels] or NULL: the buffer this view's mi_rast_backward will accumulate dL_dcolor into.  When not
                                      NULL the forward leaves it ZERO-FILLED (what torch::zeros does in CF/rasterize_points.cu:153): the
                                      blend kernel, which is bound by VALU issue, stores the zeros beside its own work instead of a
-                                     separate 4 P channels-byte fill pass in front of the backward */
+                                     separate 4 P channels-byte fill pass in front of the backward (while the zeros are no more
+                                     than the image bytes it stores anyway; a larger buffer is filled by a fill command here) */
     void* stream,
     int* num_rendered /* [host] */);
 

@@ -335,19 +335,21 @@ def test_cull_is_exactly_conservative(case):
         hp.assert_close(k + " (cull off vs on)", g_off[k], want, rtol=2e-4, flip_frac=max(hp.GRAD_FLIP_FRAC, 1.5 / max(1, want.size)))
 
 
-@pytest.mark.parametrize("C,kw", [(3, {}), (3, {"use_mask": True}), (32, {}), (48, {}), (64, {}), (16, {}), (32, {"tile_fwd": True})])
+@pytest.mark.parametrize("C,kw", [(3, {}), (3, {"use_mask": True}), (32, {}), (48, {}), (64, {}), (16, {}), (32, {"tile_fwd": True}),
+                                  (32, {"P": 60_000, "W": 64, "H": 48})])
 def test_forward_prefills_the_backward_accumulators(C, kw):
     """include/mi_rast.h dL_dcolor_next / MI_RAST_PREZERO_BWD: the forward's blend kernel leaves the backward's accumulators --
     the (P, channels) dL_dcolor buffer and the packed field gradients + work-queue counters in the geometry buffer -- zero-filled
     (what torch::zeros does in CF/rasterize_points.cu:153-159), and the backward then skips its fills.  Checked with NaN /
     0xFF left in the allocator's free blocks, for the wave-per-quadrant kernels (RGB, RGB + mask + depth, 32, 64, 48 = 32 + 16:
     the first block's launch takes the fill), for kernels that do not take it (16 channels; the tile-batched forward: fill
-    commands), and with an odd P (the (P, 3) buffer is not a whole number of 16-byte units).  Gradients equal those of a plain run."""
+    commands), with an odd P (the (P, 3) buffer is not a whole number of 16-byte units), and with more zeros than image (60 000
+    Gaussians on 64 x 48 pixels: the kernel takes the fill only while it at most doubles its own stores).  Gradients equal those of a plain run."""
     import torch
     from seganygaussians_amd import _lib
     kw = dict(kw)
     tile_fwd = kw.pop("tile_fwd", None)
-    P, W, H = 7001, 200, 136
+    P, W, H = kw.pop("P", 7001), kw.pop("W", 200), kw.pop("H", 136)
     inp = hp.make_inputs(P, W, H, C, seed=41, camera="orbit", bg="random", **kw)
     dL = scenes.make_grad_image(C, H, W, seed=5)
     dLm = None if inp.mask is None else (np.random.default_rng(9).normal(0, 1, (1, H, W)) / (W * H)).astype(np.float32)
