@@ -137,7 +137,10 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
     backward's accumulators zero-filled -- a (P, channels) dL_dcolors tensor allocated here and the packed field gradients
     inside the geometry buffer -- stored by the blend kernel beside its own work (include/mi_rast.h: dL_dcolor_next,
     MI_RAST_PREZERO_BWD) instead of by two fill passes in front of the backward.  The tensor is left on the returned geometry
-    buffer as `.mi_prezero`; hand it to ONE rasterize_gaussians_backward_native call (`prezeroed=`)."""
+    buffer as `.mi_prezero` (with `.mi_pack_zeroed = True`); hand both to ONE rasterize_gaussians_backward_native call
+    (`prezeroed=`, `pack_zeroed=`).  The dL_dcolors tensor is only made here while it is no larger than the image (P <= H W:
+    the kernel takes the fill while it at most doubles its own stores; a larger one is cheapest as the backward's own
+    torch.zeros, as before); prezero="always" makes it regardless (tests: the library then uses a fill command)."""
     ready = _opts.features_ready          # one-shot: consumed by THIS forward whatever happens below (P == 0, an exception)
     _opts.features_ready = None
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
@@ -160,7 +163,9 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
                                    viewmatrix, projmatrix, campos, mask)]
         bg_c, m3_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, vm_c, pm_c, cp_c, mk_c = t
         n = C.c_int(0)
-        grad_colors = torch.empty((P, channels), dtype=torch.float32, device=dev) if prezero else None
+        grad_colors = None
+        if prezero and (P <= H * W or prezero == "always"):
+            grad_colors = torch.empty((P, channels), dtype=torch.float32, device=dev)
         if with_mask_depth and (mk_c is None or mk_c.numel() != P or not mk_c.is_cuda or mk_c.dtype != torch.float32):
             # the DEPTH package always passes a mask (DEPTH/.../__init__.py:323); without one out_mask / out_depth
             # would be left unwritten
@@ -182,8 +187,10 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
         del ready
         geom.tensor.mi_flags = int(_opts.flags)   # the backward re-takes the forward's decisions: it needs the same flags
         _check(rc)
-        if grad_colors is not None:
-            geom.tensor.mi_prezero = grad_colors
+        if prezero:
+            geom.tensor.mi_pack_zeroed = True
+            if grad_colors is not None:
+                geom.tensor.mi_prezero = grad_colors
         rendered = n.value
     else:
         out_color = torch.zeros((channels, H, W), dtype=torch.float32, device=dev)
@@ -212,11 +219,12 @@ def _flags_of(geomBuffer, flags):
 def rasterize_gaussians_backward_native(channels, with_mask_depth, background, means3D, radii, colors, scales,
                                         rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
                                         tan_fovy, dL_dout_color, dL_dout_mask, sh, degree, campos, geomBuffer, R,
-                                        binningBuffer, imageBuffer, debug, flags=None, prezeroed=None):
+                                        binningBuffer, imageBuffer, debug, flags=None, prezeroed=None, pack_zeroed=None):
     """RasterizeGaussiansBackwardCUDA (CF/rasterize_points.cu:117-196; DEPTH/rasterize_points.cu).
 
     prezeroed: the zero-filled (P, channels) tensor the forward of THESE buffers produced with prezero=True, not used by any
-    backward before: it becomes dL_dcolors, and the fill of the packed field gradients is skipped as well."""
+    backward before: it becomes dL_dcolors.  pack_zeroed: that forward also left the packed field gradients in its geometry
+    buffer zeroed (None: as `prezeroed`): their fill is skipped."""
     L = _lib.load()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -244,6 +252,8 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
     flat = torch.empty(sum(sizes), **o)
     if debug:
         flat.fill_(float("nan"))
+    if pack_zeroed is None:
+        pack_zeroed = prezeroed is not None
     if prezeroed is not None and (tuple(prezeroed.shape) != (P, channels) or prezeroed.device != dev or debug):
         prezeroed = None
     g = {"dL_dcolors": prezeroed if prezeroed is not None else torch.zeros((P, channels), **o), "dL_dsh": torch.zeros((P, M, 3), **o)}
@@ -275,7 +285,7 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
                 dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
                 dL_dmask.data_ptr() if with_mask_depth else None, dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M > 0 else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(),
-                int(bool(debug)), int(_flags_of(geomBuffer, flags)) | (_lib.MI_RAST_PREZERO_BWD if prezeroed is not None else 0),
+                int(bool(debug)), int(_flags_of(geomBuffer, flags)) | (_lib.MI_RAST_PREZERO_BWD if pack_zeroed else 0),
                 _stream_ptr(dev))
         _check(rc)
     if with_mask_depth:
@@ -391,7 +401,8 @@ def _make_plain(channels):
             ctx.raster_settings = rs
             ctx.num_rendered = num_rendered
             ctx.mi_flags = getattr(geomBuffer, "mi_flags", 0)
-            ctx.mi_prezero = geomBuffer.__dict__.pop("mi_prezero", None)   # one-shot: the first backward takes it
+            ctx.mi_prezero = geomBuffer.__dict__.pop("mi_prezero", None)   # one-shot: the first backward takes them
+            ctx.mi_pack_zeroed = bool(geomBuffer.__dict__.pop("mi_pack_zeroed", False))
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                                   binningBuffer, imgBuffer)
             ctx.mark_non_differentiable(radii)
@@ -413,12 +424,13 @@ def _make_plain(channels):
                     geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug)
 
             prezeroed, ctx.mi_prezero = ctx.mi_prezero, None   # (a second backward through a retained graph fills for itself)
+            pack_zeroed, ctx.mi_pack_zeroed = ctx.mi_pack_zeroed, False
 
             def call():
                 (bg, m3, rad, col, sc, rot, smod, cov, vm, pm, tx, ty, gout, sh_, deg, cp, gb, nr, bb, ib, dbg) = args
                 return rasterize_gaussians_backward_native(channels, False, bg, m3, rad, col, sc, rot, smod, cov, vm,
                                                            pm, tx, ty, gout, None, sh_, deg, cp, gb, nr, bb, ib, dbg,
-                                                           flags=ctx.mi_flags, prezeroed=prezeroed)
+                                                           flags=ctx.mi_flags, prezeroed=prezeroed, pack_zeroed=pack_zeroed)
 
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)

@@ -59,19 +59,21 @@ def test_autograd_through_dropin(pkg, C):
     assert torch.equal(c2, color.detach())
 
 
-def test_second_backward_through_a_retained_graph():
+@pytest.mark.parametrize("W,H", [(160, 112), (48, 32)])
+def test_second_backward_through_a_retained_graph(W, H):
     """The forward hands its pre-zeroed accumulators (rasterizer.py: prezero) to ONE backward; a second backward through a
-    retained graph must fill its own and give the same gradients."""
+    retained graph must fill its own and give the same gradients.  48 x 32: more Gaussians than pixels -- only the packed
+    field gradients are pre-zeroed, dL_dcolors is the backward's own torch.zeros."""
     import diff_gaussian_rasterization_contrastive_f as mod
     dev = torch.device("cuda:0")
-    inp = hp.make_inputs(5000, 160, 112, 32, seed=33, camera="orbit")
+    inp = hp.make_inputs(5000, W, H, 32, seed=33, camera="orbit")
     means3D, feats = _leaf(inp.means3D, dev), _leaf(inp.colors_precomp, dev)
     opac, scales, rots = _leaf(inp.opacities, dev), _leaf(inp.scales, dev), _leaf(inp.rotations, dev)
     means2D = torch.zeros_like(means3D, requires_grad=True)
     rast = mod.GaussianRasterizer(raster_settings=_settings(mod, inp, dev))
     color, _ = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=feats, opacities=opac, scales=scales,
                     rotations=rots, cov3D_precomp=None)
-    dL = torch.as_tensor(scenes.make_grad_image(32, 112, 160, seed=6)).to(dev)
+    dL = torch.as_tensor(scenes.make_grad_image(32, H, W, seed=6)).to(dev)
     color.backward(dL, retain_graph=True)
     first = {k: v.grad.clone() for k, v in (("feats", feats), ("means3D", means3D), ("opac", opac))}
     color.backward(dL)

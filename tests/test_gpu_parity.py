@@ -359,8 +359,9 @@ def test_forward_prefills_the_backward_accumulators(C, kw):
     dev = plain.dev
     junk = [torch.full((P, C), float("nan"), device=dev), torch.full((int(plain.geom.numel()),), 0xFF, dtype=torch.uint8, device=dev)]
     del plain, junk
-    run = hp.GpuRun(inp).forward(full_lists=False, tile_fwd=tile_fwd, prezero=True)
+    run = hp.GpuRun(inp).forward(full_lists=False, tile_fwd=tile_fwd, prezero="always")   # ("always": also when P > H W)
     pre = run.geom.mi_prezero
+    assert run.geom.mi_pack_zeroed is True
     torch.cuda.synchronize()
     assert tuple(pre.shape) == (P, C) and pre.dtype == torch.float32
     assert int(torch.count_nonzero(pre.view(torch.int32))) == 0, "dL_dcolor_next not zero-filled"

@@ -54,7 +54,9 @@ with open(os.path.join(dst, f"{tag}_kernel_stats{sfx}.md"), "w") as f:
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         f.write(f"| `{k}` | {c} | {t/1e6:.3f} | {t/c/1e3:.1f} | {100*t/tot:.2f} |\n")
-    f.write(f"\nUn-profiled bench line of the same build (`python bench.py --config {cfg} --steps 20 --warmup 3`):\n\n```json\n" + bench_line + "\n```\n")
+    f.write(f"\nUn-profiled bench line of the same build (`python bench.py --config {cfg} --steps 20 --warmup 3`), printed on the box right after the "
+            "passes above -- i.e. BEFORE this build's PMC summaries existed, hence `traffic` / `alu` null and `pmc: ... ignored` in it; the lines "
+            f"with the summaries in place are in profiles/{tag}_bench_lines.md:\n\n```json\n" + bench_line + "\n```\n")
 
 
 def pmc(name):
