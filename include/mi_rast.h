@@ -15,9 +15,12 @@
  *    reference's "empty tensor -> nullptr" convention (CF/.../__init__.py:196-206).
  *  - fp32, contiguous; out_color / dL_dpix are CHW; colors_precomp is (P,C); shs is (P,M,3).
  *  - `channels` is the reference's compile-time NUM_CHANNELS (config.h:15 = 3,
- *    config_contrastive_f.h:15 = 32), a RUN-TIME argument here; supported: 3 and every multiple of 16 up to 256
+ *    config_contrastive_f.h:15 = 32), a RUN-TIME argument here; supported: every width from 1 to 256
  *    (mi_rast_supported_channels()).  32 and 64 run in one pass of the blend kernels, other widths in channel blocks of
- *    64 / 32 / 16, one pass each (e.g. 112 = 64 + 32 + 16); anything else returns MI_RAST_ERR_INVALID.
+ *    64 / 32 / 16, one pass each (e.g. 112 = 64 + 32 + 16); a width that is no multiple of 16 ends in a PARTIAL 16-channel block
+ *    (100 = 64 + 32 + 4 of 16: zeros in the matrix operands behind the real channels, as RGB -- 3 of 16 -- is rendered; rows of such
+ *    a feature are not 16-byte aligned, which the vector loads of the full blocks tolerate at reduced speed); 0 or more than 256
+ *    returns MI_RAST_ERR_INVALID.
  *  - `mask != NULL` selects the DEPTH variant (adds out_mask/out_depth, dL_dmask).
  *  - `stream` is a hipStream_t (0 = null stream).  The rendering entry points are RE-ENTRANT: they keep no
  *    state between calls (every mode is a per-call argument: `flags`, `features_ready_event`), all memory is
@@ -58,6 +61,12 @@ extern "C" {
                                   the reference (n_contrib differs on ~1e-5 of the pixels, the per-row gradient noise is ~10x the
                                   reference's own; still inside the 1e-4 contract).  The backward MUST be given the flags of its
                                   forward: it re-takes the same decisions */
+#define MI_RAST_EXACT_EXP 128  /* forward blend: the device library's expf for EVERY pair.  Product default (flag clear): the hybrid form of
+                                  csrc/common.h -- v_exp_f32(x * log2e) away from the alpha >= 1/255 cut, expf for every pair of list entries
+                                  in which some pixel comes within 4e-6 (relative) of it: the decisions are expf's always (the backward,
+                                  which uses expf, re-takes exactly them), alpha itself differs by <= 1e-6 relative, the image by ~1e-7
+                                  of its scale; cfg3 forward blend 0.283 -> see DESIGN.md section 11.  With the flag, alpha / T / n_contrib /
+                                  final_T are bit-identical to a build of the reference's kernels (tests) */
 #define MI_RAST_VERIFY_LISTS 16 /* debugging aid (lean lists only; synchronous): zero-fills the list entries before the emit pass and
                                 * fails with MI_RAST_ERR_HIP if a slot the count pass reserved was not written by the emit pass */
 #define MI_RAST_TILE_FWD 32    /* 32/64-channel forward on the tile-batched bf16x3 kernel (four lockstep waves per tile, blend_fwd_x3.h)

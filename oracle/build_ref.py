@@ -16,6 +16,7 @@ Variants (one .so each; the reference fixes NUM_CHANNELS at compile time, CF/cud
     cf32    CF/    NUM_CHANNELS 32   diff_gaussian_rasterization_contrastive_f  (the headline path)
     cf64    CF/    NUM_CHANNELS 64   what a user builds for 64-D features (cfg5)
     cf16 / cf128  CF/  NUM_CHANNELS 16 / 128   (parity of the product's channel blocks: any multiple of 16)
+    cf8 / cf40 / cf100  CF/  NUM_CHANNELS 8 / 40 / 100   (widths that end in a partial 16-channel block)
     base3   BASE/  NUM_CHANNELS 3    diff_gaussian_rasterization
     depth3  DEPTH/ NUM_CHANNELS 3    diff_gaussian_rasterization_depth (mask + depth + mask-only pair)
     knn     simple-knn/simple_knn.cu  (distCUDA2's core, SimpleKNN::knn)
@@ -51,6 +52,9 @@ VARIANTS = {
     "cf64": ("cf", 64, [], "off"),
     "cf16": ("cf", 16, [], "off"),      # the narrowest / widest feature the product's channel blocks cover in the parity tests
     "cf128": ("cf", 128, [], "off"),
+    "cf8": ("cf", 8, [], "off"),        # widths that are no multiple of 16: the product's last channel block is partial
+    "cf40": ("cf", 40, [], "off"),
+    "cf100": ("cf", 100, [], "off"),
     "base3": ("base", 3, ["-DREF_BASE"], "off"),
     "depth3": ("depth", 3, ["-DREF_DEPTH"], "off"),
 }

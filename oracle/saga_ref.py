@@ -26,7 +26,7 @@ def available(variant: str) -> bool:
 def variant_for(channels: int, with_mask: bool) -> str:
     if with_mask:
         return "depth3"
-    return {3: "base3", 16: "cf16", 32: "cf32", 64: "cf64", 128: "cf128"}[channels]
+    return {3: "base3", 8: "cf8", 16: "cf16", 32: "cf32", 40: "cf40", 64: "cf64", 100: "cf100", 128: "cf128"}[channels]
 
 
 def lib(variant: str):

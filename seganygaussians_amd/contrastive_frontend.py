@@ -72,19 +72,27 @@ class _ContrastiveFrontEnd(torch.autograd.Function):
             raise RuntimeError("contrastive_front_end needs GPU tensors: the front end has no CPU fallback "
                                "(sample_scale_conditioned_features is the PyTorch restatement the tests compare with)")
         L = _lib.load()
+        ctx.in_dtypes = (rendered.dtype, gates.dtype)
+        dev = rendered.device
         rendered = rendered.contiguous().float()
+        # everything the kernels dereference lives on `rendered`'s device (contrastive_front_end moves what is elsewhere; a CPU
+        # index tensor would hand the kernels a host pointer)
+        if gates.device != dev or ray_yx.device != dev:
+            raise RuntimeError(f"gates ({gates.device}) and ray coordinates ({ray_yx.device}) must be on the device of the "
+                               f"rendered features ({dev})")
         gates_c = gates.contiguous().float()
+        ray_yx = ray_yx.to(torch.int32).contiguous()
         C, h, w = rendered.shape
         N, S = gates_c.shape[0], ray_yx.shape[0]
-        dev = rendered.device
         out = torch.empty((N, S, C), device=dev, dtype=torch.float32)
         ray_feat = torch.empty((S, C), device=dev, dtype=torch.float32)
         inv_len = torch.empty((N, S), device=dev, dtype=torch.float32)
         inv_norm = torch.empty((h * w,), device=dev, dtype=torch.float32)
         norm_sum = torch.zeros((64 * 16,), device=dev, dtype=torch.float64)   # MI_CONTRASTIVE_NORM_SLOTS partial sums, one per 128-byte line
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        rc = L.mi_contrastive_forward(C, h, w, rendered.data_ptr(), int(H), int(W), S, _ptr(ray_yx), N, gates_c.data_ptr(),
-                                      _ptr(out), _ptr(ray_feat), _ptr(inv_len), inv_norm.data_ptr(), norm_sum.data_ptr(), stream)
+        with torch.cuda.device(dev):   # the launch pairs the stream with the CURRENT device
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.mi_contrastive_forward(C, h, w, rendered.data_ptr(), int(H), int(W), S, _ptr(ray_yx), N, gates_c.data_ptr(),
+                                          _ptr(out), _ptr(ray_feat), _ptr(inv_len), inv_norm.data_ptr(), norm_sum.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError(_lib.last_error())
         ctx.save_for_backward(rendered, gates_c, ray_yx, out, ray_feat, inv_len, inv_norm)
@@ -104,13 +112,15 @@ class _ContrastiveFrontEnd(torch.autograd.Function):
         if d_out_c is None and S > 0:
             d_out_c = torch.zeros((N, S, C), device=dev, dtype=torch.float32)
         g = None if d_norm is None else d_norm.reshape(1).contiguous().float()
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        rc = L.mi_contrastive_backward(C, h, w, rendered.data_ptr(), H, W, S, _ptr(ray_yx), N, gates_c.data_ptr(), _ptr(out),
-                                       _ptr(ray_feat), _ptr(inv_len), inv_norm.data_ptr(), _ptr(d_out_c), _ptr(g),
-                                       d_rendered.data_ptr(), d_gates.data_ptr(), stream)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.mi_contrastive_backward(C, h, w, rendered.data_ptr(), H, W, S, _ptr(ray_yx), N, gates_c.data_ptr(), _ptr(out),
+                                           _ptr(ray_feat), _ptr(inv_len), inv_norm.data_ptr(), _ptr(d_out_c), _ptr(g),
+                                           d_rendered.data_ptr(), d_gates.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError(_lib.last_error())
-        return d_rendered, d_gates, None, None, None
+        # gradients in the dtype (and, for the gates, on the device) the inputs came in
+        return d_rendered.to(ctx.in_dtypes[0]), d_gates.to(ctx.in_dtypes[1]), None, None, None
 
 
 def contrastive_front_end(rendered_features: torch.Tensor, out_hw, sampled_ray: torch.Tensor, gates: torch.Tensor):
@@ -124,6 +134,9 @@ def contrastive_front_end(rendered_features: torch.Tensor, out_hw, sampled_ray: 
     tensor of (y, x) ray coordinates in row-major order; gates (N, C).  Returns (scale_conditioned (N, S, C),
     rendered_feature_norm scalar); both differentiable w.r.t. rendered_features and gates."""
     H, W = int(out_hw[0]), int(out_hw[1])
+    dev = rendered_features.device
+    gates = gates.to(dev)               # (differentiable moves: the gradient returns to where the tensor came from)
+    sampled_ray = sampled_ray.to(dev)
     if sampled_ray.dtype == torch.bool:
         if sampled_ray.shape != (H, W):
             raise ValueError(f"sampled_ray has shape {tuple(sampled_ray.shape)}, expected {(H, W)}")

@@ -28,6 +28,21 @@
 
 namespace mirast {
 
+
+// ---- exp() of the backward ---------------------------------------------------------------------------------------------
+// The backward re-takes the forward's alpha >= 1/255 decisions, so near that cut it needs the forward's G bit for bit
+// (common.h: gauss_exp<true>, the device library's expf, 10 VALU).  Away from the cut it only needs G to a few ulp: every
+// use is a float-path quantity.  MI_BWD_HYBRID_EXP: G = v_exp_f32(power * log2e) (2 instructions; relative error
+// <= |power| * 1.5 * 2^-24 + 1 ulp <= 7e-7 wherever opacity * G can reach 1/255, i.e. power >= -5.55), and a group of
+// rows in which ANY lane's opacity * G lies within 1.5e-6 (relative) of 1/255 is re-evaluated with the exact form (a
+// wave-uniform branch, taken for ~1e-4 of the groups).  Outside that band both forms fall on the same side of the
+// cut: the decisions are the forward's, always.
+#ifndef MI_BWD_HYBRID_EXP
+#define MI_BWD_HYBRID_EXP 0
+#endif
+#ifndef MI_BWD_SEPMOM
+#define MI_BWD_SEPMOM 0
+#endif
 // 1 / x to ~0.5 ulp: v_rcp_f32 (1 ulp) plus one Newton step (two FMAs).  T is divided by (1 - alpha) once per row and the
 // quotients are chained through the whole list: the reference uses a correctly rounded division there (backward.cu:487).
 #ifndef MI_BWD_RCP_REFINE
@@ -39,6 +54,10 @@ __device__ __forceinline__ float rcp_refined(float x)
     if (MI_BWD_RCP_REFINE) r = fmaf(fmaf(-x, r, 1.0f), r, r);
     return r;
 }
+constexpr float ALPHA_CUT_BAND = 1.5e-6f * ALPHA_CUT;
+// min(0.99, t) for t >= -1 as ONE instruction: v_med3_f32.  fminf() on a value that comes out of a select costs two (hipcc
+// canonicalises it first, v_max_f32 x, x, because the kernel runs in IEEE mode); the result is the same operand either way.
+__device__ __forceinline__ float alpha_clamp(float t) { return __builtin_amdgcn_fmed3f(t, 0.99f, -1.0f); }
 
 template <int C>
 struct BwvCfg {
@@ -48,7 +67,9 @@ struct BwvCfg {
     static constexpr int FEAT4 = CHK * FROW / 4;
 };
 
-// C: channels as the MFMA tiling sees them (16, 32, 64); CR: channels in memory (CR == C, or 3 for RGB padded to C = 16).
+// C: channels as the MFMA tiling sees them (16, 32, 64); CR: channels in memory (CR == C; 3 for RGB padded to C = 16; 0: `cr_arg`
+// (1 .. 15) of a 16-channel block are real -- the last block of a feature whose width is no multiple of 16, the reference compiles
+// ANY NUM_CHANNELS (config_contrastive_f.h:15) -- with rows `cstride_arg` floats apart).
 // WPB: waves (quadrants) per workgroup, 1 or 4 -- the waves of a workgroup never synchronise either way.
 // STRIDED: rows of `colors` / `dL_dcolors` are `cstride_arg` floats apart (one channel block of a wider feature); otherwise CR.
 template <int C, int CR = C, bool MASKGRAD = false, int WPB = 1, bool XEXP = false, bool STRIDED = false>
@@ -61,16 +82,21 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     uint32_t* __restrict__ queue_ctr /* eight zeroed work-queue counters (common.h: xcd_grab) */,
     int cstride_arg /* STRIDED: floats between the rows of two Gaussians in `colors` and `dL_dcolors` = the full channel count of
                        the feature this launch handles one channel block of (both pointers then point at the block) */,
+    int cr_arg /* CR == 0: channels of this block that exist in memory */,
     int ablate /* timing experiments: profiling build only (common.h: MI_ABLATE) */)
 {
     constexpr int FROW = BwvCfg<C>::FROW, QCAP = BwvCfg<C>::QCAP, FEAT4 = BwvCfg<C>::FEAT4;
     const int cstride = STRIDED ? cstride_arg : CR;   // (a compile-time constant in the common case: no 64-bit multiply, no extra registers)
+    const int cr = CR == 0 ? cr_arg : CR;             // channels in memory (a constant unless CR == 0)
     constexpr int CPL = C / 4;   // channels per lane in the S contraction: lane (n16, kq) holds channels CPL*kq .. +CPL-1
     constexpr int NB = C / 16;   // 16-channel blocks of the dF contraction
     constexpr int F4 = C / 4;    // float4s per feature row
     constexpr int NK = (CHK * F4 + 63) / 64;  // float4 feature parts per lane and chunk
-    constexpr int MROW = 16;                  // floats per row of the moment / field staging (6 moments; 8 fields)
-    static_assert(CR == C || (C == 16 && CR == 3), "padded layout is the RGB case only");
+    // floats per row of the moment / field staging.  MI_BWD_SEPMOM: 4 y-quarters x 12 slots of partial moments (then 8 fields);
+    // otherwise 6 moments (then 8 fields)
+    constexpr int MROW = MI_BWD_SEPMOM ? 48 : 16;
+    static_assert(CR == C || (C == 16 && (CR == 3 || CR == 0)), "padded layouts: RGB, or a partial 16-channel block");
+    static_assert(CR != 0 || STRIDED, "a partial block is a block of a wider (or narrower) feature: its row stride is an argument");
     static_assert(!MASKGRAD || CR == 3, "the mask gradient belongs to the RGB (DEPTH variant) kernel");
     static_assert(2 * CHK * WROW >= 64 * DLROW, "gradient-image staging must fit in the w/u rows");
 
@@ -113,7 +139,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     float dLpix[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) {
-        if (ch < CR) dLpix[ch] = dL_dpixels[(size_t)ch * HW + pix_safe];
+        if (ch < cr) dLpix[ch] = dL_dpixels[(size_t)ch * HW + pix_safe];
         else if (MASKGRAD && ch == CR) dLpix[ch] = dL_dout_mask[pix_safe];
         else dLpix[ch] = 0.f;
     }
@@ -151,7 +177,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
 #pragma unroll
             for (int c = 0; c < PASS; c++) {
                 const float v = inside ? dLpix[PASS * h + c] : 0.f;
-                if (PASS * h + c < CR) bg_dot_dpixel += bg_color[PASS * h + c] * v;
+                if (PASS * h + c < cr) bg_dot_dpixel += bg_color[PASS * h + c] * v;
                 stage[lane * DLROW + c] = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -179,10 +205,17 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     const bool has_bg = ballot64(nTb != 0.f) != 0;   // wave-uniform
     const int last4 = last_contributor << 4, wave_Lt4 = wave_Lt << 4;  // compared with (position << 4 | mask)
 
+    // MI_BWD_SEPMOM (default): the six moments are separable, x^a y^b.  Stage 1 contracts over x on the matrix pipe with
+    // v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks, K = 1, 8 cycles): block (row group rg = (lane >> 2) & 3, pixel row
+    // y = kq + 4 set) takes A = u[row 4 rg + (lane & 3)][pixel 8 y + t] and B = x_t^a with a = lane & 3 (a = 3: zero) for
+    // t = 0..7, and leaves X_a[row 4 rg + v][y] in register v of lane (rg, y, a): 16 MFMA x 8 cycles per chunk instead of
+    // 16 x 32 for M = U^T Phi with 6 of 16 columns in use.  Stage 2 (the sum over y with weights 1, y, y^2) is 20 VALU
+    // in-lane for the two sets plus a sum over the four y quarters by the row's lane when it reads the partials back.
+    // Otherwise:
     // Phi[pixel 16kq+s][j = n16] = monomial j (1, x, y, x^2, xy, y^2) about the quadrant centre, x = (s&7) - 3.5 (a
     // literal per unrolled step), y = 2kq - 3.5 + (s>>3):  phi = P[s>>3] + Q[s>>3] x + R x^2  (exact: small dyadics)
     float phP[2], phQ[2], phR;
-    {
+    if constexpr (!MI_BWD_SEPMOM) {
         const float c1 = n16 == 0, cx = n16 == 1, cy = n16 == 2, cxx = n16 == 3, cxy = n16 == 4, cyy = n16 == 5;
 #pragma unroll
         for (int v = 0; v < 2; v++) {
@@ -192,6 +225,9 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
         }
         phR = cxx;
     }
+    // separable path: B_t = c0 + c1 x_t + c2 x_t^2 selects x_t^a for this lane's a = lane & 3; y of set 0 / set 1
+    const float sm_c0 = (lane & 3) == 0, sm_c1 = (lane & 3) == 1, sm_c2 = (lane & 3) == 2;
+    const float sm_y0 = (float)(lane >> 4) - 3.5f, sm_y1 = (float)(lane >> 4) + 0.5f;
 
     float Rcur = 0.f;  // sum over the Gaussians behind the current one of (their colour . dL) * their share of what is behind
     // wave-uniform constants, pinned to SGPRs (as VGPRs they get spilled, and a scratch reload in the middle of a chunk waits
@@ -250,6 +286,10 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             const size_t gid = (size_t)s_queue[(qh + g) & (QCAP - 1)].y;
             if constexpr (CR == C) {
                 featpf[k] = reinterpret_cast<const float4*>(colors + gid * (size_t)cstride)[part];
+            } else if constexpr (CR == 0) {  // partial block: channel by channel, zeros behind cr (never reads past the row)
+                const float* row = colors + gid * (size_t)cstride + 4 * part;
+                featpf[k] = make_float4(4 * part + 0 < cr ? row[0] : 0.f, 4 * part + 1 < cr ? row[1] : 0.f,
+                                        4 * part + 2 < cr ? row[2] : 0.f, 4 * part + 3 < cr ? row[3] : 0.f);
             } else {  // RGB: three floats per Gaussian (part 0); the other 13 operand channels are zero
                 featpf[k] = make_float4(colors[gid * (size_t)cstride + 0], colors[gid * (size_t)cstride + 1], colors[gid * (size_t)cstride + 2], 0.f);
             }
@@ -294,7 +334,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
                 const int e = lane + 64 * k;
                 const int g = e / F4, part = e % F4;
                 float4 f = featpf[k];
-                if (CR != C && part != 0) f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (CR == 3 && part != 0) f = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!FULL && g >= nrows) f = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_feat4[g * (FROW / 4) + part] = f;
             }
@@ -347,12 +387,18 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
             const float dx = p0.x - pixfx, dy = p0.y - pixfy;
             const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-            const float G = gauss_exp<XEXP>(power);
+            const bool can = (__float_as_int(p1.z) < last4) && power <= 0.0f;
             // opacity * G where the row can blend into this pixel at all, else 0; the 1/255 cut is the last test
             // (min(0.99, t) >= 1/255  <=>  t >= 1/255)
-            const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;
-            const float tG = t0 >= (1.0f / 255.0f) ? t0 : 0.f;   // opacity * G of a contributing row
-            const float alpha = fminf(0.99f, tG);
+            float t0;
+            if constexpr (XEXP && MI_BWD_HYBRID_EXP) {
+                t0 = can ? p1.y * gauss_exp_fast(power) : 0.f;
+                if (ballot64(fabsf(t0 - ALPHA_CUT) <= ALPHA_CUT_BAND) != 0) t0 = can ? p1.y * gauss_exp<true>(power) : 0.f;
+            } else {
+                t0 = can ? p1.y * gauss_exp<XEXP>(power) : 0.f;
+            }
+            const float tG = t0 >= ALPHA_CUT ? t0 : 0.f;   // opacity * G of a contributing row
+            const float alpha = alpha_clamp(tG);
             const float om = 1.f - alpha;
             const float inv = rcp_refined(om);
             T = T * inv;
@@ -369,6 +415,8 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
         // row's own reciprocal): bg = 0 is SAGA's feature training (train_contrastive_feature.py:98).
         auto row_group4 = [&](const int r0) __attribute__((always_inline)) {
             float tG[4], al[4], om[4];
+            constexpr bool HYB = XEXP && MI_BWD_HYBRID_EXP;
+            bool band = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int rr = r0 + k;
@@ -376,10 +424,28 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
                 const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
                 const float dx = p0.x - pixfx, dy = p0.y - pixfy;
                 const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-                const float G = gauss_exp<XEXP>(power);
+                const float G = HYB ? gauss_exp_fast(power) : gauss_exp<XEXP>(power);
                 const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;
-                tG[k] = t0 >= (1.0f / 255.0f) ? t0 : 0.f;
-                al[k] = fminf(0.99f, tG[k]);
+                if constexpr (HYB) band = band || fabsf(t0 - ALPHA_CUT) <= ALPHA_CUT_BAND;
+                tG[k] = t0 >= ALPHA_CUT ? t0 : 0.f;
+            }
+            if constexpr (HYB) {
+                if (ballot64(band) != 0) {  // some lane sits on the cut: the forward's own exp decides (rare; rows re-read from LDS)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int rr = r0 + k;
+                        const float4 p0 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar));
+                        const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
+                        const float dx = p0.x - pixfx, dy = p0.y - pixfy;
+                        const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
+                        const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * gauss_exp<true>(power) : 0.f;
+                        tG[k] = t0 >= ALPHA_CUT ? t0 : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                al[k] = alpha_clamp(tG[k]);
                 om[k] = 1.f - al[k];
             }
             float Tk[4];
@@ -420,24 +486,46 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) facc[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
         v4f macc = (v4f){0.f, 0.f, 0.f, 0.f};
+        v4f xacc0 = (v4f){0.f, 0.f, 0.f, 0.f}, xacc1 = (v4f){0.f, 0.f, 0.f, 0.f};  // MI_BWD_SEPMOM: X_a[row][y] of set 0 / set 1
         {
             const float4* wrow = reinterpret_cast<const float4*>(my_wa + n16 * WROW + 16 * kq);
             const float4* urow = reinterpret_cast<const float4*>(my_ua + n16 * WROW + 16 * kq);
+            // separable moments: this lane's row is 4 rg + (lane & 3) = n16, its pixel rows kq and kq + 4
+            const float4* urow_s0 = reinterpret_cast<const float4*>(my_ua + n16 * WROW + 8 * kq);
+            const float4* urow_s1 = reinterpret_cast<const float4*>(my_ua + n16 * WROW + 8 * kq + 32);
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
                 const float4 wv = wrow[s4];
-                const float4 uv = urow[s4];
                 const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
-                const float ua[4] = {uv.x, uv.y, uv.z, uv.w};
+                float ua[4], ub[4];
+                if constexpr (MI_BWD_SEPMOM) {
+                    if (s4 < 2) {  // pixels 4 s4 .. 4 s4 + 3 of the lane's two pixel rows
+                        const float4 u0 = urow_s0[s4], u1 = urow_s1[s4];
+                        ua[0] = u0.x, ua[1] = u0.y, ua[2] = u0.z, ua[3] = u0.w;
+                        ub[0] = u1.x, ub[1] = u1.y, ub[2] = u1.z, ub[3] = u1.w;
+                    }
+                } else {
+                    const float4 uv = urow[s4];
+                    ua[0] = uv.x, ua[1] = uv.y, ua[2] = uv.z, ua[3] = uv.w;
+                }
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     const int s = 4 * s4 + t;
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++)
                         facc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[nb][s], facc[nb], 0, 0, 0);
-                    const float x = (float)(s & 7) - 3.5f;
-                    const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
-                    macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
+                    if constexpr (MI_BWD_SEPMOM) {
+                        if (s4 < 2) {
+                            const float x = (float)s - 3.5f;  // s = 0..7: the pixel column
+                            const float xa = fmaf(x, fmaf(x, sm_c2, sm_c1), sm_c0);
+                            xacc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ua[t], xa, xacc0, 0, 0, 0);
+                            xacc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(ub[t], xa, xacc1, 0, 0, 0);
+                        }
+                    } else {
+                        const float x = (float)(s & 7) - 3.5f;
+                        const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
+                        macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -453,9 +541,9 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             // across the whole kernel -- and spilled)
             uint32_t gid = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row * (int)sizeof(BwdPar) + 28));
 #ifdef MI_RAST_PROFILING
-            // timing experiments on the atomics (wrong results): 8192 = every quadrant adds to rows of its
-            // own (no line is shared by the quadrants of a tile); 16384 = only the lowest quadrant of a record's mask adds (the
-            // request count a perfect (tile, record) reduction would leave, at no cost for the reduction itself)
+            // timing experiments on the atomics (wrong results): 8192 = every quadrant adds to rows of its own (no line is shared
+            // by the quadrants of a tile); 16384 = only the lowest quadrant of a record's mask adds (the request count a perfect
+            // (tile, record) reduction would leave)
             const uint32_t pm_row = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row * (int)sizeof(BwdPar) + 24));
             if (MI_ABLATE(8192)) gid = (gid + quad * 250007u) % 1000000u;
             const bool lowest_q = ((pm_row & 15u) & (0u - (pm_row & 15u))) == (1u << quad);
@@ -472,24 +560,50 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
                 if constexpr (CR == C) {
                     atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], facc[nb][r]);
                 } else {
-                    if (ch < CR) atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], facc[nb][r]);
+                    if (ch < cr) atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], facc[nb][r]);
                     else if (MASKGRAD && ch == CR) atomicAdd(&gpack[(size_t)gid * 8 + 6], facc[nb][r]);
                 }
             }
         }
         // (a separate, unconditional loop: with the store inside the loop above and guarded by n16 < 8, hipcc clones the
         // atomics into both arms of the guard -- twice the memory instructions, and a count that depends on the path)
+        if constexpr (MI_BWD_SEPMOM) {
+            // stage 2: Z_b = y0^b X(set 0) + y1^b X(set 1), b = 0, 1, 2, for the four rows 4 rg + v this lane holds, stored at
+            // slot 3 a + b of the (row, y quarter) group of 12 floats: {M0, M2 (y), M5 (y^2)} {M1 (x), M4 (xy), -} {M3 (x^2), -, -} {-, -, -}
+            int l = threadIdx.x & 63;
+            asm volatile("" : "+v"(l));  // (per-chunk address arithmetic: hoisted out of the chunk loop it would be spilled)
+            float* const mbase = my_mom + ((l >> 2) & 3) * (4 * MROW) + 12 * (l >> 4) + 3 * (l & 3);
+            const float y0 = sm_y0, y1 = sm_y1, y0q = sm_y0 * sm_y0, y1q = sm_y1 * sm_y1;
 #pragma unroll
-        for (int r = 0; r < 4; r++) my_mom[(4 * kq + r) * MROW + n16] = macc[r];
+            for (int v = 0; v < 4; v++) {
+                mbase[v * MROW + 0] = xacc0[v] + xacc1[v];
+                mbase[v * MROW + 1] = fmaf(y1, xacc1[v], y0 * xacc0[v]);
+                mbase[v * MROW + 2] = fmaf(y1q, xacc1[v], y0q * xacc0[v]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) my_mom[(4 * kq + r) * MROW + n16] = macc[r];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // moments -> fields: lane = row (16 lanes) rewrites its my_mom row in place, then the wave adds the rows
         // to the packed per-Gaussian records: lane -> (row = l / 8 (+8), field = l % 8), 32 contiguous bytes per row
         {
             if (lane < 16) {
                 const int row = lane;
-                const float4 m0 = reinterpret_cast<const float4*>(my_mom + row * MROW)[0];
-                const float4 m1 = reinterpret_cast<const float4*>(my_mom + row * MROW)[1];
-                const float M0 = m0.x, M1 = m0.y, M2 = m0.z, M3 = m0.w, M4 = m1.x, M5 = m1.y;
+                float4 m0 = reinterpret_cast<const float4*>(my_mom + row * MROW)[0];
+                float4 m1 = reinterpret_cast<const float4*>(my_mom + row * MROW)[1];
+                float M0, M1, M2, M3, M4, M5;
+                if constexpr (MI_BWD_SEPMOM) {  // sum over the four y quarters; slots {M0, M2, M5, M1} {M4, -, M3, -}
+#pragma unroll
+                    for (int q = 1; q < 4; q++) {
+                        const float4 a0 = reinterpret_cast<const float4*>(my_mom + row * MROW)[3 * q];
+                        const float4 a1 = reinterpret_cast<const float4*>(my_mom + row * MROW)[3 * q + 1];
+                        m0.x += a0.x, m0.y += a0.y, m0.z += a0.z, m0.w += a0.w, m1.x += a1.x, m1.z += a1.z;
+                    }
+                    M0 = m0.x, M2 = m0.y, M5 = m0.z, M1 = m0.w, M4 = m1.x, M3 = m1.z;
+                } else {
+                    M0 = m0.x, M1 = m0.y, M2 = m0.z, M3 = m0.w, M4 = m1.x, M5 = m1.y;
+                }
                 const float ca = -2.f * mine.q0.z, cb = -mine.q0.w, cc = -2.f * mine.q1.x, op = mine.q1.y;
                 const float gx = mine.q0.x - cxq, gy = mine.q0.y - cyq;
                 // dx = gx - x', dy = gy - y'

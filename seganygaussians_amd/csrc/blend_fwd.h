@@ -37,7 +37,11 @@ struct FeatStage {
     static constexpr int ROW = (CE + 3) & ~3;
 };
 
-template <int C, int EXTRA, bool XEXP = false>
+// PARTIAL: only the first `cr` (< C) of the block's C channels exist in memory -- the last channel block of a feature whose width
+// is no multiple of 16 (the reference compiles ANY NUM_CHANNELS, config_contrastive_f.h:15): feature rows are staged channel by
+// channel with zeros behind cr (a vector load would run into the next Gaussian's row, or past the end of the tensor), and only cr
+// planes are written.
+template <int C, int EXTRA, bool XEXP = false, bool PARTIAL = false>
 __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fwd_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
     int W, int H, const float* __restrict__ features, const float* __restrict__ mask, const float* __restrict__ depths,
@@ -46,11 +50,14 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fw
     float* __restrict__ out_mask, float* __restrict__ out_depth,
     int cstride /* floats between the feature rows of two Gaussians: C, or the full channel count when this launch renders one
                    channel block of a wider feature (mi_rast.hip: channel blocks; `features` then points at the block) */,
+    int cr_arg /* PARTIAL: channels of this block that exist (1 .. C - 1) */,
     int ablate /* timing experiments only (MI_RAST_ABLATE_FWD); 0 in production */)
 {
+    const int cr = PARTIAL ? cr_arg : C;
     constexpr int CE = C + EXTRA;            // accumulated values per pixel
     constexpr int ROW = FeatStage<CE>::ROW;  // LDS floats per staged Gaussian
-    constexpr bool VEC_STAGE = (EXTRA == 0) && (C % 4 == 0) && (C >= 4);
+    constexpr bool VEC_STAGE = (EXTRA == 0) && (C % 4 == 0) && (C >= 4) && !PARTIAL;
+    static_assert(!PARTIAL || (EXTRA == 0 && C == 16), "partial blocks are the 16-channel remainder of a feature");
     constexpr bool USE_MFMA = (EXTRA == 0) && (C == 32 || C == 64);
     constexpr int NACC = USE_MFMA ? C / 32 : 1;  // 32-channel accumulator tiles
     typedef float v32f __attribute__((ext_vector_type(32)));
@@ -122,7 +129,8 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fw
             s_pm[tid] = cur.pm;
             if constexpr (!VEC_STAGE) {
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) s_feat[tid * ROW + ch] = features[(size_t)cur.id * cstride + ch];
+                for (int ch = 0; ch < C; ch++)
+                    s_feat[tid * ROW + ch] = (!PARTIAL || ch < cr) ? features[(size_t)cur.id * cstride + ch] : 0.f;
                 if constexpr (EXTRA >= 1) s_feat[tid * ROW + C] = mask[cur.id];
                 if constexpr (EXTRA >= 2) s_feat[tid * ROW + C + 1] = depths[cur.id];
             }
@@ -293,7 +301,8 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fw
         }
     } else if (inside) {
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix_id] = acc[ch] + T * bg_color[ch];
+        for (int ch = 0; ch < C; ch++)
+            if (!PARTIAL || ch < cr) out_color[ch * HW + pix_id] = acc[ch] + T * bg_color[ch];
         if constexpr (EXTRA >= 1) out_mask[pix_id] = acc[C];
         if constexpr (EXTRA >= 2) out_depth[pix_id] = acc[C + 1];
     }

@@ -1,6 +1,6 @@
 // blend_fwd_wave.h -- forward blend for C = 32 / 64, one WAVE per 8x8 quadrant, no workgroup barriers.
 //
-// Same per-pixel arithmetic as blend_fwd_x3.h (renderCUDA<C> forward, CF/cuda_rasterizer/forward.cu:264-385: alpha, T, the
+// Same per-pixel arithmetic as blend_fwd.h (renderCUDA<C> forward, CF/cuda_rasterizer/forward.cu:264-385: alpha, T, the
 // 1/255 and 1e-4 tests, n_contrib and final_T on f32 VALU code, bit-identical) and the same accumulation (every f32 operand
 // split exactly into three bf16 terms, six partial products on the bf16 matrix pipe, f32 accumulate).  What changes is who
 // walks the tile's blend list and when -- the restructuring blend_bwd_wave.h applied to the backward:
@@ -16,7 +16,10 @@
 //   * the group's records sit at fixed LDS offsets (entry i at s_rec[i]): no per-quadrant index lists.
 #pragma once
 
-#include "blend_fwd_x3.h"
+#include <type_traits>
+
+#include "blend_fwd.h"
+#include "blend_fwd_split.h"
 
 namespace mirast {
 
@@ -66,7 +69,8 @@ __device__ __forceinline__ void fwd_zero_fill(const FwdZeroFill& z, uint32_t wg,
 #define MI_FWD_WAVES64 3
 #endif
 
-template <int C, bool XEXP = false, bool STRIDED = false>
+// XM: how opacity * exp(power) is evaluated (common.h: ExpMode) -- EXP_HYBRID is the product default.
+template <int C, int XM = EXP_HYBRID, bool STRIDED = false>
 __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64) blend_fwd_wave_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features, float* __restrict__ final_T,
@@ -202,39 +206,73 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
         if (nnext > 0) request_rows(nnext);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-        // ---- 3. alpha, T and w of the 16 entries (same f32 arithmetic as blend_fwd.h), w split and packed in pairs
+        // ---- 3. alpha, T and w of the 16 entries (same f32 arithmetic as blend_fwd.h), w split and packed in pairs.
+        // EXP_HYBRID: the whole group is evaluated with v_exp_f32 first (no branch inside: hipcc interleaves the pairs); `band`
+        // collects the lanes of any entry whose opacity * G falls between the two bounds around the 1/255 cut, and in that (rare)
+        // case the group is evaluated again from the saved pixel state with expf for every entry -- a wave-uniform branch per
+        // GROUP (one per pair of entries was measured: the branches and their scalar mask arithmetic ate what the exp saved).
         uint32_t wp[3][XG / 2];
         int fin_j = -1;
+        auto eval_group = [&](auto fast_tag) __attribute__((always_inline)) -> uint64_t {
+            constexpr bool FAST = decltype(fast_tag)::value;   // v_exp_f32 + two bounds; otherwise expf (or XM's own form) + the cut
+            uint64_t band = 0;
 #pragma unroll
-        for (int i = 0; i < XG / 2; i++) {
-            if (2 * i >= n || live == 0) {  // padding pair of the wave's last group, or every pixel is done (wave-uniform): w = 0
-                wp[0][i] = wp[1][i] = wp[2][i] = 0u;
-                continue;
-            }
-            float w2[2];
+            for (int i = 0; i < XG / 2; i++) {
+                if (2 * i >= n || live == 0) {  // padding pair of the wave's last group, or every pixel is done (wave-uniform): w = 0
+                    wp[0][i] = wp[1][i] = wp[2][i] = 0u;
+                    continue;
+                }
+                float w2[2];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const float4 p0 = *reinterpret_cast<const float4*>(rec_bytes + (2 * i + h) * (int)sizeof(XRec));
-                const float4 p1 = *reinterpret_cast<const float4*>(rec_bytes + (2 * i + h) * (int)sizeof(XRec) + 16);
-                const float dx = p0.x - pixfx, dy = p0.y - pixfy;
-                const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-                const float t = p1.y * gauss_exp<XEXP>(power);
-                const float alpha = fminf(0.99f, t);
-                const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);
-                const float test_T = T * (1 - alpha);
-                // forward.cu:358-362: done once a contributor would push T below 1e-4 (that one is not blended).
-                const float tt = ok ? test_T : 1.0f;
-                live &= ~__builtin_amdgcn_fcmpf(tt, 0.0001f, 4 /* FCMP_OLT */);
-                const bool stop = tt < 0.0001f;
-                done = done || stop;
-                const bool blend = ok && !stop;
-                w2[h] = blend ? alpha * T : 0.f;
-                T = blend ? test_T : T;
-                last_contributor = blend ? __float_as_uint(p1.z) : last_contributor;
-                fin_j = (live == 0 && fin_j < 0) ? 2 * i + h : fin_j;  // first entry after which nobody is left
+                for (int h = 0; h < 2; h++) {
+                    const float4 p0 = *reinterpret_cast<const float4*>(rec_bytes + (2 * i + h) * (int)sizeof(XRec));
+                    const float4 p1 = *reinterpret_cast<const float4*>(rec_bytes + (2 * i + h) * (int)sizeof(XRec) + 16);
+                    const float dx = p0.x - pixfx, dy = p0.y - pixfy;
+                    const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
+                    float t;
+                    bool cut;
+                    if constexpr (FAST) {
+                        t = p1.y * gauss_exp_fast(power);
+                        cut = t >= ALPHA_CUT_HI;
+                        band |= ballot64(t >= ALPHA_CUT_LO) ^ ballot64(cut);
+                    } else {
+                        t = p1.y * gauss_exp<XM != EXP_FAST>(power);
+                        cut = t >= ALPHA_CUT;
+                    }
+                    const float alpha = fminf(0.99f, t);
+                    const bool ok = !done && power <= 0.0f && cut;
+                    const float test_T = T * (1 - alpha);
+                    // forward.cu:358-362: done once a contributor would push T below 1e-4 (that one is not blended).
+                    const float tt = ok ? test_T : 1.0f;
+                    live &= ~__builtin_amdgcn_fcmpf(tt, 0.0001f, 4 /* FCMP_OLT */);
+                    const bool stop = tt < 0.0001f;
+                    done = done || stop;
+                    const bool blend = ok && !stop;
+                    w2[h] = blend ? alpha * T : 0.f;
+                    T = blend ? test_T : T;
+                    last_contributor = blend ? __float_as_uint(p1.z) : last_contributor;
+                    fin_j = (live == 0 && fin_j < 0) ? 2 * i + h : fin_j;  // first entry after which nobody is left
+                }
+                split3_bf16x2(w2[0], w2[1], wp[0][i], wp[1][i], wp[2][i]);
+                __builtin_amdgcn_sched_barrier(0);  // keeps the record reads of later pairs from piling up in registers
             }
-            split3_bf16x2(w2[0], w2[1], wp[0][i], wp[1][i], wp[2][i]);
-            __builtin_amdgcn_sched_barrier(0);  // keeps the record reads of later pairs from piling up in registers
+            return band;
+        };
+        if constexpr (XM == EXP_HYBRID) {
+            const float T0 = T;
+            const bool done0 = done;
+            const uint32_t last0 = last_contributor;
+            const uint64_t live0 = live;
+            if (eval_group(std::true_type{}) != 0) {   // some lane sits on the cut: expf decides (and supplies the values), for the whole group
+                T = T0;
+                done = done0;
+                last_contributor = last0;
+                live = live0;
+                fin_j = -1;
+                eval_group(std::false_type{});
+            }
+        } else {
+            eval_group(std::false_type{});
         }
         if (fin_j >= 0) {
             consumed = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rec[fin_j].q1.z));
@@ -335,7 +373,7 @@ namespace mirast {
 // The same walk for RGB (C = 3; EXTRA = 2: the DEPTH variant's mask and depth planes, DEPTH/cuda_rasterizer/forward.cu:308-309,
 // 363-365, 384-385, no background term on them): accumulators on the VALU (acc[ch] = fmaf(f[ch], w, acc[ch]) in list order --
 // the arithmetic of blend_fwd.h, bit for bit), the 16 rows of a group staged as {r, g, b, mask, depth} floats.
-template <int EXTRA, bool XEXP = false>
+template <int EXTRA, int XM = EXP_HYBRID>
 __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features /* [P,3] */,
@@ -452,9 +490,21 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
             const float4 p1 = *reinterpret_cast<const float4*>(rec_bytes + i * (int)sizeof(XRec) + 16);
             const float dx = p0.x - pixfx, dy = p0.y - pixfy;
             const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-            const float t = p1.y * gauss_exp<XEXP>(power);
+            float t;
+            bool cut;
+            if constexpr (XM == EXP_HYBRID) {   // common.h: v_exp_f32 away from the 1/255 cut, expf on it
+                t = p1.y * gauss_exp_fast(power);
+                cut = t >= ALPHA_CUT_HI;
+                if ((ballot64(t >= ALPHA_CUT_LO) ^ ballot64(cut)) != 0) {
+                    t = p1.y * gauss_exp<true>(power);
+                    cut = t >= ALPHA_CUT;
+                }
+            } else {
+                t = p1.y * gauss_exp<XM == EXP_EXACT>(power);
+                cut = t >= ALPHA_CUT;
+            }
             const float alpha = fminf(0.99f, t);
-            const bool ok = !done && power <= 0.0f && t >= (1.0f / 255.0f);
+            const bool ok = !done && power <= 0.0f && cut;
             const float test_T = T * (1 - alpha);
             const float tt = ok ? test_T : 1.0f;
             live &= ~__builtin_amdgcn_fcmpf(tt, 0.0001f, 4 /* FCMP_OLT */);

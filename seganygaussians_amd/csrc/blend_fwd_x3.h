@@ -22,32 +22,11 @@
 #pragma once
 
 #include "blend_fwd.h"
+#include "blend_fwd_split.h"
 
 namespace mirast {
 
 constexpr int XB = 128;    // blend-list records per batch
-// a staged feature row: bf16 hi[C] | mid[C] | lo[C], i.e. 6 C bytes (192 at C = 32)
-constexpr int XG = 16;     // Gaussians per MFMA group
-
-// One staged record: {x, y, -a/2, -b} {-c/2, opacity, list position + 1, (position << 4 | quadrant mask)}
-struct XRec {
-    float4 q0, q1;
-};
-
-typedef float v16f __attribute__((ext_vector_type(16)));
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));  // one MFMA operand: 8 bf16
-typedef float v2fx __attribute__((ext_vector_type(2)));
-typedef __bf16 v2bfx __attribute__((ext_vector_type(2)));
-
-// (a, b) -> three dwords holding a's term in the low and b's term in the high half-word: a = hi + mid + lo exactly
-__device__ __forceinline__ void split3_bf16x2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo)
-{
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2fx){a, b}, v2bfx));
-    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-    mid = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2fx){ra, rb}, v2bfx));
-    const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2fx){sa, sb}, v2bfx));
-}
 
 // C = 64: two 32-channel accumulator pairs (64 VGPRs), 24 MFMA per group, rows of 384 bytes: 2 workgroups per CU.
 template <int C, bool XEXP = false, bool STRIDED = false>

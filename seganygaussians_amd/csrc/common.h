@@ -149,6 +149,21 @@ __device__ __forceinline__ float gauss_power(float ha, float nb, float hc, float
 // pl ends in ldexp(inf, INT_MIN) = inf.  Where the two differ the blend kernels do not use the value: power > 0 and NaN are
 // rejected by their own `power <= 0` test (forward.cu:339), and opacity times a denormal fails the >= 1/255 test like
 // opacity times 0.
+//
+// HYBRID evaluation (the forward blend's product default, blend_fwd_wave.h; include/mi_rast.h: MI_RAST_EXACT_EXP switches it off):
+// opacity * exp(power) only has to be the device expf's value BIT FOR BIT where it decides something -- at the alpha >= 1/255
+// cut, which the backward re-takes with expf.  Away from the cut a few ulp are float-path noise (alpha to ~6e-7 relative).  So:
+// G = v_exp_f32(power * log2e) (2 VALU; relative error <= 8 * 2^-24 * ln 2 + 1 ulp < 1e-6 wherever opacity * G can reach 1/255,
+// i.e. power >= -5.55), two compares against the cut widened by +-4e-6 relative, and a pair of entries in which ANY lane falls
+// between the two bounds is re-evaluated with the exact form (a wave-uniform branch, taken for ~1e-4 of the pairs).  A value
+// outside the band lies on the same side of the cut in both forms, so every decision is the one expf takes: the forward and the
+// backward agree on who blends, always.
+constexpr float ALPHA_CUT = 1.0f / 255.0f;
+constexpr float ALPHA_CUT_LO = (float)((1.0 / 255.0) * (1.0 - 4e-6));
+constexpr float ALPHA_CUT_HI = (float)((1.0 / 255.0) * (1.0 + 4e-6));
+enum ExpMode : int { EXP_FAST = 0, EXP_EXACT = 1, EXP_HYBRID = 2 };
+__device__ __forceinline__ float gauss_exp_fast(float power) { return __builtin_amdgcn_exp2f(power * 0x1.715476p+0f); }
+
 template <bool XEXP>
 __device__ __forceinline__ float gauss_exp(float power)
 {

@@ -27,7 +27,9 @@
 #include "blend_bwd_wave.h"
 #include "blend_fwd.h"
 #include "blend_fwd_wave.h"
-#include "blend_fwd_x3.h"
+#ifdef MI_RAST_PROFILING
+#include "blend_fwd_x3.h"   // round 2's tile-batched bf16x3 forward: A/B comparisons only (MI_RAST_TILE_FWD)
+#endif
 #include "common.h"
 #include "contrastive.h"
 #include "geometry.h"
@@ -334,8 +336,11 @@ inline size_t bwd_pack_bytes(int P)
 {
     return (size_t)(P > 0 ? P : 1) * 8 * sizeof(float) + MAX_CHANNEL_BLOCKS * 8 * XCD_QUEUE_STRIDE * sizeof(uint32_t);
 }
-bool channels_supported(int c) { return c == 3 || (c >= 16 && c <= MAX_CHANNELS && c % 16 == 0); }
-// next block of a feature with `rem` channels left
+// Any width from 1 to MAX_CHANNELS (the reference compiles ANY NUM_CHANNELS into its kernels, config_contrastive_f.h:15): blocks of
+// 64 / 32 / 16 channels, the last one possibly PARTIAL -- fewer than 16 real channels, zeros in the MFMA operands behind them, as
+// RGB has always been rendered (3 of 16).
+bool channels_supported(int c) { return c >= 1 && c <= MAX_CHANNELS; }
+// next block of a feature with `rem` channels left (rem < 16: a 16-channel block of which `rem` exist)
 int channel_block(int rem) { return rem >= 64 ? 64 : (rem >= 32 ? 32 : 16); }
 
 // Stages shared by forward and mask_forward: CF/cuda_rasterizer/rasterizer_impl.cu:246-317.
@@ -464,6 +469,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                                    stream, P, geom.rank_rec, img.tile_count, (const uint2*)nullptr, (uint32_t*)nullptr, vp.grid_x,
                                    vp.grid_y, by0, by1, g_ablate_fwd);
         }
+        // (one launch for both scans -- every workgroup scans its tiles over the slices, the last one to finish scans the totals
+        // behind a device-scope counter and agent-scope fences -- was built and measured in round 4: depth order 0.079 -> 0.086 ms,
+        // tile scan 0.058 -> 0.060 ms on cfg3; the fences and the serial tail inside the kernel cost more than the launch they save)
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
@@ -565,19 +573,26 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
 template <int C, int EXTRA>
 void launch_blend_fwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin,
                       const GeomPtrs& geom, const float* features, const float* mask, const float* bg,
-                      float* out_color, float* out_mask, float* out_depth, bool xexp, int cstride = C)
+                      float* out_color, float* out_mask, float* out_depth, bool xexp, int cstride = C, int cr = C)
 {
     const int g_ablate_fwd = ablate_env("MI_RAST_ABLATE_FWD");
-    if (xexp)
-        hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA, true>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                           bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
-                           img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, cstride, g_ablate_fwd);
-    else
-        hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA, false>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                           bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,
-                           img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, cstride, g_ablate_fwd);
+#define TILE_FWD_LAUNCH(XE, PART)                                                                                                     \
+    hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA, XE, PART>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,              \
+                       bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,              \
+                       img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, cstride, cr, g_ablate_fwd)
+    if constexpr (C == 16 && EXTRA == 0) {   // the remainder block of a feature: `cr` < 16 of its channels may exist (blend_fwd.h PARTIAL)
+        if (cr < C) {
+            if (xexp) TILE_FWD_LAUNCH(true, true);
+            else TILE_FWD_LAUNCH(false, true);
+            return;
+        }
+    }
+    if (xexp) TILE_FWD_LAUNCH(true, false);
+    else TILE_FWD_LAUNCH(false, false);
+#undef TILE_FWD_LAUNCH
 }
 
+#ifdef MI_RAST_PROFILING
 template <int C>
 void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const float* features,
                          const float* bg, float* out_color, bool xexp, int cstride)
@@ -595,47 +610,51 @@ void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs
     }
 #undef X3_LAUNCH
 }
+#endif
 
 // One wave per (tile, quadrant): 32 x the longest XCD run of tiles workgroups (blend_fwd_wave.h).
+// xm: common.h ExpMode -- EXP_HYBRID unless the caller's flags say otherwise (exp_mode_of)
 template <int C>
 void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const float* features,
-                           const float* bg, float* out_color, bool xexp, int cstride, FwdZeroFill& zfill)
+                           const float* bg, float* out_color, int xm, int cstride, FwdZeroFill& zfill)
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
     const uint32_t grid = 32u * ((nt + 7u) >> 3);
     const FwdZeroFill zf = zfill;
     zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};   // taken: the launches of further channel blocks fill nothing
-#define FW_LAUNCH(XE, ST)                                                                                                     \
-    hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XE, ST>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec,            \
+#define FW_LAUNCH(XM, ST)                                                                                                     \
+    hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XM, ST>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec,            \
                        img.blend_count, vp.W, vp.H, vp.grid_x, nt, features, img.final_T, img.n_contrib, img.tile_consumed,       \
                        img.tile_nsurv, bg, out_color, cstride, zf)
-    if (cstride == C) {
-        if (xexp) FW_LAUNCH(true, false);
-        else FW_LAUNCH(false, false);
-    } else {
-        if (xexp) FW_LAUNCH(true, true);
-        else FW_LAUNCH(false, true);
-    }
+#define FW_LAUNCH_ST(ST)                                  \
+    do {                                                  \
+        if (xm == EXP_HYBRID) FW_LAUNCH(EXP_HYBRID, ST);  \
+        else if (xm == EXP_EXACT) FW_LAUNCH(EXP_EXACT, ST); \
+        else FW_LAUNCH(EXP_FAST, ST);                     \
+    } while (0)
+    if (cstride == C) FW_LAUNCH_ST(false);
+    else FW_LAUNCH_ST(true);
+#undef FW_LAUNCH_ST
 #undef FW_LAUNCH
 }
 
 template <int EXTRA>
 void launch_blend_fwd_wave_rgb(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const GeomPtrs& geom,
                                const float* features, const float* mask, const float* bg, float* out_color, float* out_mask,
-                               float* out_depth, bool xexp, FwdZeroFill& zfill)
+                               float* out_depth, int xm, FwdZeroFill& zfill)
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
     const uint32_t grid = 32u * ((nt + 7u) >> 3);
     const FwdZeroFill zf = zfill;
     zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};
-    if (xexp)
-        hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, true>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec, img.blend_count,
-                           vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,
-                           img.tile_nsurv, bg, out_color, out_mask, out_depth, zf);
-    else
-        hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, false>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec, img.blend_count,
-                           vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,
-                           img.tile_nsurv, bg, out_color, out_mask, out_depth, zf);
+#define RGB_LAUNCH(XM)                                                                                                                       \
+    hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, XM>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec, img.blend_count,    \
+                       vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,                 \
+                       img.tile_nsurv, bg, out_color, out_mask, out_depth, zf)
+    if (xm == EXP_HYBRID) RGB_LAUNCH(EXP_HYBRID);
+    else if (xm == EXP_EXACT) RGB_LAUNCH(EXP_EXACT);
+    else RGB_LAUNCH(EXP_FAST);
+#undef RGB_LAUNCH
 }
 
 template <int C, bool MASKGRAD>
@@ -707,9 +726,7 @@ const char* mi_rast_version(void) { return "mi_rast 0.3 (gfx950) src:" MI_RAST_S
 int mi_rast_supported_channels(int* out, int n)
 {
     int k = 0;
-    if (k < n) out[k] = 3;
-    k++;
-    for (int c = 16; c <= MAX_CHANNELS; c += 16, k++)
+    for (int c = 1; c <= MAX_CHANNELS; c++, k++)
         if (k < n) out[k] = c;
     return k;
 }
@@ -977,7 +994,7 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
     hipStream_t stream = (hipStream_t)stream_;
     if (num_rendered) *num_rendered = 0;
     if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
-    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3 and the multiples of 16 up to 256)");
+    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 1 .. 256)");
     if (mask && channels != 3) return fail(MI_RAST_ERR_INVALID, "mask/depth variant is built for 3 channels");
     // CF/cuda_rasterizer/rasterizer_impl.cu:242-245
     if (channels != 3 && colors_precomp == nullptr)
@@ -1030,36 +1047,58 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
             if (flags & MI_RAST_PREZERO_BWD)
                 if ((rc = region(geom.bwd_pack, bwd_pack_bytes(P), zfill.b, zfill.nb))) return rc;
         }
-        const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;
-        const bool tile_fwd_rgb = (flags & MI_RAST_TILE_FWD) != 0;   // the tile-batched kernels instead of the wave-per-quadrant ones
-        if (mask && tile_fwd_rgb) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
-        else if (mask) launch_blend_fwd_wave_rgb<2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp, zfill);
-        else if (channels == 3 && tile_fwd_rgb) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
-        else if (channels == 3) launch_blend_fwd_wave_rgb<0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp, zfill);
-        else {
+        const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;   // the kernels without a hybrid form: expf unless MI_RAST_FAST_EXP
+        const int xm = (flags & MI_RAST_FAST_EXP) ? EXP_FAST : (flags & MI_RAST_EXACT_EXP) ? EXP_EXACT : EXP_HYBRID;   // the wave-per-quadrant kernels
+        // Product kernels: the wave-per-quadrant forward (RGB, RGB + mask + depth, 64- and 32-channel blocks) and the tile-batched kernel for
+        // the 16-channel remainder block.  The comparison kernels of earlier rounds -- MI_RAST_TILE_FWD (tile-batched bf16x3 / RGB),
+        // MI_RAST_F32_BLEND (f32 FMA chain) -- exist in the profiling build only (libmi_rast_prof.so, seganygaussians_amd/build.py).
+#ifdef MI_RAST_PROFILING
+        const bool tile_fwd = (flags & MI_RAST_TILE_FWD) != 0, f32_blend = (flags & MI_RAST_F32_BLEND) != 0;
+#else
+        constexpr bool tile_fwd = false, f32_blend = false;
+        if (flags & (MI_RAST_TILE_FWD | MI_RAST_F32_BLEND))
+            return fail(MI_RAST_ERR_INVALID, "MI_RAST_TILE_FWD / MI_RAST_F32_BLEND select comparison kernels of the profiling build "
+                                             "(libmi_rast_prof.so: python -m seganygaussians_amd.build --profiling, MI_RAST_LIB=<path>)");
+#endif
+        if (mask || channels == 3) {
+#ifdef MI_RAST_PROFILING
+            if (tile_fwd && mask) launch_blend_fwd<3, 2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xexp);
+            else if (tile_fwd) launch_blend_fwd<3, 0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xexp);
+            else
+#endif
+            if (mask) launch_blend_fwd_wave_rgb<2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xm, zfill);
+            else launch_blend_fwd_wave_rgb<0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xm, zfill);
+        } else {
             // feature channels in blocks of 64 / 32 / 16 (one launch per block; see channels_supported)
             const size_t HW = (size_t)width * height;
-            const bool f32_blend = (flags & MI_RAST_F32_BLEND) != 0;   // f32 FMA-chain forward (include/mi_rast.h)
-            const bool tile_fwd = (flags & MI_RAST_TILE_FWD) != 0;     // the tile-batched bf16x3 forward (blend_fwd_x3.h) instead of the wave kernel
             for (int c0 = 0; c0 < channels;) {
                 const int cb = channel_block(channels - c0);
                 const float* f = feature_ptr + c0;
                 const float* bgp = background + c0;
                 float* out = out_color + (size_t)c0 * HW;
                 if (cb == 64) {
+#ifdef MI_RAST_PROFILING
                     if (f32_blend) launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
                     else if (tile_fwd) launch_blend_fwd_x3<64>(vp, stream, img, bin, f, bgp, out, xexp, channels);
-                    else launch_blend_fwd_wave<64>(vp, stream, img, bin, f, bgp, out, xexp, channels, zfill);
+                    else
+#endif
+                    launch_blend_fwd_wave<64>(vp, stream, img, bin, f, bgp, out, xm, channels, zfill);
                 } else if (cb == 32) {
+#ifdef MI_RAST_PROFILING
                     if (f32_blend) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
                     else if (tile_fwd) launch_blend_fwd_x3<32>(vp, stream, img, bin, f, bgp, out, xexp, channels);
-                    else launch_blend_fwd_wave<32>(vp, stream, img, bin, f, bgp, out, xexp, channels, zfill);
+                    else
+#endif
+                    launch_blend_fwd_wave<32>(vp, stream, img, bin, f, bgp, out, xm, channels, zfill);
                 } else {
-                    launch_blend_fwd<16, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
+                    launch_blend_fwd<16, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels,
+                                            std::min(16, channels - c0));
                 }
                 c0 += cb;
             }
         }
+        (void)tile_fwd;
+        (void)f32_blend;
         // no wave-per-quadrant launch took the fill (tile-batched / f32 / 16-channel kernels): fill commands
         if (zfill.na) HIP_TRY(hipMemsetAsync(zfill.a, 0, (size_t)zfill.na << 4, stream));
         if (zfill.nb) HIP_TRY(hipMemsetAsync(zfill.b, 0, (size_t)zfill.nb << 4, stream));
@@ -1082,7 +1121,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     const bool xexp = (flags & MI_RAST_FAST_EXP) == 0;
     const int g_ablate = ablate_env("MI_RAST_ABLATE");
     (void)g_ablate;
-    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 3 and the multiples of 16 up to 256)");
+    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 1 .. 256)");
     const bool maskgrad = dL_dmask != nullptr;
     if (maskgrad && (channels != 3 || !dL_dout_mask)) return fail(MI_RAST_ERR_INVALID, "mask gradient needs 3 channels and dL_dout_mask");
 
@@ -1102,6 +1141,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         const float* dpix_blk = dL_dpix;
         float* dcolor_blk = dL_dcolor;
         int cstride = channels;
+        int cr_blk = 0;   // channels of a partial block that exist (blend_bwd_wave.h: CR == 0)
 #define LAUNCH_BWD_MFMA(...)                                                                                              \
     hipLaunchKernelGGL((blend_bwd_mfma_kernel<__VA_ARGS__>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,    \
                        bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib, dL_dpix, \
@@ -1110,7 +1150,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
 #define LAUNCH_BWD_WAVE_(WPB, XE, ST, ...)                                                                                    \
     hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE, ST>), dim3(WPB == 1 ? 32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_) : nt_), dim3(64 * WPB), 0,    \
                        stream, img.ranges, bin.blend_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
-                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, g_ablate)
+                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk, g_ablate)
 #ifdef MI_RAST_PROFILING
 #define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
     do {                                                                            \
@@ -1156,9 +1196,11 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
                 colors_blk = color_ptr + c0;
                 dpix_blk = dL_dpix + (size_t)c0 * HW;
                 dcolor_blk = dL_dcolor + c0;
+                cr_blk = std::min(cb, channels - c0);
                 if (cb == 64) LAUNCH_BWD_WAVE(64, 64, false);
                 else if (cb == 32) LAUNCH_BWD_WAVE(32, 32, false);
-                else LAUNCH_BWD_WAVE(16, 16, false);
+                else if (cr_blk == 16) LAUNCH_BWD_WAVE(16, 16, false);
+                else LAUNCH_BWD_WAVE_ST(true, 16, 0, false);   // partial block: cr_blk of its 16 channels exist
                 queue_ctr += 8 * XCD_QUEUE_STRIDE;
                 c0 += cb;
             }

@@ -23,12 +23,15 @@ from . import _lib
 from .rasterizer import _check, _dev_ptr, _stream_ptr
 
 
+FUSED_MAX_K = 32   # neighbours per row the fused kernels handle (include/mi_knn_smooth.h)
+
+
 class NeighbourMap:
     """knn_idx [P, K] (int32 on the GPU) plus the inverse lists the backward walks, built once per map
     (the reference caches `feature_smooth_map` the same way, gaussian_model_ff.py:345-352)."""
 
     def __init__(self, knn_idx: torch.Tensor):
-        if knn_idx.dim() != 2 or knn_idx.size(1) < 1 or knn_idx.size(1) > 32:
+        if knn_idx.dim() != 2 or knn_idx.size(1) < 1 or knn_idx.size(1) > FUSED_MAX_K:
             raise ValueError("knn_idx must have shape (P, K) with 1 <= K <= 32")
         if not knn_idx.is_cuda:
             raise RuntimeError("knn_idx must be on the GPU: the fused smoothing has no CPU path")
@@ -131,6 +134,14 @@ def fused_get_smoothed_point_features(self, K=16, dropout=0.5):
     normalise -> gather -> mean and its backward in the fused kernels instead of PyTorch's (P, k, C) gather and index_put."""
     if K <= 1:
         return self._point_features
+    # The fused kernels keep a row's K neighbours in registers (K <= 32) and the HIP search returns K real neighbours (K <= P);
+    # the reference expression takes any smooth_K and pytorch3d pads: outside those limits it is the reference's own method
+    # that runs (INTEGRATION.md section 5).
+    if K > FUSED_MAX_K or K > self._point_features.shape[0]:
+        ref = getattr(type(self), "_reference_get_smoothed_point_features", None)
+        if ref is None:
+            raise ValueError(f"fused feature smoothing supports K <= {FUSED_MAX_K} and K <= number of points; got K={K}")
+        return ref(self, K, dropout)
     assert dropout < 0 or int(K * dropout) >= 1
     with torch.no_grad():
         if self.feature_smooth_map is None or self.feature_smooth_map["K"] != K:

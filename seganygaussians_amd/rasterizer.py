@@ -103,23 +103,26 @@ class _CallOptions(threading.local):
     def __init__(self):
         self.flags = 0
         self.features_ready = None   # torch.cuda.Event, kept alive until the forward that consumes it has returned
+        self.grad_mode = True        # torch.is_grad_enabled() of the CALLER (autograd switches it off inside Function.forward)
 
 
 _opts = _CallOptions()
 
 
 @contextlib.contextmanager
-def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None):
+def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None, exact_exp=None):
     """Within the block, forwards of this thread run with the given modes: `full_lists` materialises the reference's
     point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels, `no_cull` switches the exact-conservative cull off (testing aid), `fast_exp` evaluates exp() as
     v_exp_f32(x * log2e) instead of the device library's expf the reference's kernels call (+2 % views/s, ~5 ulp: a few
     alpha >= 1/255 decisions differ from the reference's); `verify_lists` (debugging aid) checks that the count and emit passes of the
-    lean lists agree slot by slot.  The flags of a
+    lean lists agree slot by slot; `exact_exp` makes the forward blend call expf for every pair (product default: the hybrid form of
+    csrc/common.h -- same decisions, alpha to 1e-6): alpha / T / n_contrib / final_T are then bit-identical to a build of the
+    reference's kernels.  The flags of a
     forward are remembered with its buffers and handed to its backward."""
     prev = _opts.flags
     for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend), (_lib.MI_RAST_NO_CULL, no_cull),
                    (_lib.MI_RAST_FAST_EXP, fast_exp), (_lib.MI_RAST_VERIFY_LISTS, verify_lists),
-                   (_lib.MI_RAST_TILE_FWD, tile_fwd)):
+                   (_lib.MI_RAST_TILE_FWD, tile_fwd), (_lib.MI_RAST_EXACT_EXP, exact_exp)):
         if v is not None:
             _opts.flags = (_opts.flags | bit) if v else (_opts.flags & ~bit)
     try:
@@ -145,6 +148,7 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
     _opts.features_ready = None
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _check_widths(channels, background, colors, means3D.size(0))
     L = _lib.load()
     P, H, W = means3D.size(0), int(image_height), int(image_width)
     dev = means3D.device
@@ -201,6 +205,19 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
     return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
 
 
+def _check_widths(channels, background, colors, P):
+    """The reference compiles NUM_CHANNELS into its kernels, which then index `bg_color[ch]` and `colors[id * C + ch]` for every
+    ch < C without a check (forward.cu:343-374, backward.cu:446-535).  Here the width is a run-time argument (the contrastive_f
+    drop-in reads it off `colors_precomp`), so a background left over from another width, or a colour tensor of another width
+    than the call says, is caught instead of read out of bounds."""
+    if background is None or background.numel() < channels:   # (a longer one is harmless: the kernels read bg[0 .. channels))
+        raise RuntimeError(f"bg must hold one value per channel: {0 if background is None else background.numel()} given, "
+                           f"{channels} channels rendered")
+    if colors is not None and colors.numel() != 0 and P != 0 and (colors.ndimension() != 2 or colors.size(0) != P
+                                                                  or colors.size(1) != channels):
+        raise RuntimeError(f"colors_precomp must have dimensions (num_points, {channels}); got {tuple(colors.shape)}")
+
+
 def set_features_ready_event(event) -> None:
     """The next forward of this host thread makes its stream wait for `event` (a recorded torch.cuda.Event, or None to
     cancel) right before its blend stage; everything before it -- preprocess, depth order, binning, per-tile sort -- only
@@ -230,6 +247,9 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
     dev = means3D.device
+    _check_widths(channels, background, colors, P)
+    if dL_dout_color.ndimension() != 3 or dL_dout_color.size(0) != channels:
+        raise RuntimeError(f"dL_dout_color must have dimensions ({channels}, H, W); got {tuple(dL_dout_color.shape)}")
     o = dict(device=dev, dtype=torch.float32)
     # The reference allocates ten zero tensors (rasterize_points.cu:151-159).  Same tensors here: dL_dcolors and dL_dsh,
     # which the kernels accumulate into, zero-filled; the others carved from ONE uninitialised block that
@@ -381,7 +401,10 @@ def _make_plain(channels):
                     rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
 
             # a backward will follow: its accumulators are zero-filled by the forward's blend kernel (rasterize_gaussians_native)
-            prezero = bool(any(ctx.needs_input_grad)) and not rs.debug and not os.environ.get("MI_RAST_NO_PREZERO")   # (env: A/B aid)
+            # (needs_input_grad is requires_grad of the inputs whatever the grad mode: render.py's no_grad forwards of a model whose
+            # parameters require grad would zero 128 MB per view for a backward that never comes)
+            prezero = (_opts.grad_mode and bool(any(ctx.needs_input_grad)) and not rs.debug
+                       and not os.environ.get("MI_RAST_NO_PREZERO"))   # (env: A/B aid)
 
             def call():
                 (bg, m3, col, op, sc, rot, smod, cov, vm, pm, tx, ty, ih, iw, sh_, deg, cp, pre, dbg) = args
@@ -449,6 +472,7 @@ def _make_plain(channels):
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                             raster_settings):
+        _opts.grad_mode = torch.is_grad_enabled()
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                          cov3Ds_precomp, raster_settings)
 

@@ -10,6 +10,7 @@ or out.  Such flips are allowed for a tiny fraction of elements (FLIP_FRAC) and 
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 
@@ -66,6 +67,27 @@ def inputs_from_config(name, P=None, seed=0, with_shs=False, use_mask=False, cam
     return inp
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF_LIB = os.path.join(ROOT, "seganygaussians_amd", "libmi_rast_prof.so")
+
+
+def rerun_with_profiling_library(request) -> bool:
+    """The comparison kernels of earlier rounds (MI_RAST_TILE_FWD, MI_RAST_F32_BLEND: tile-batched and f32-chain forwards) are
+    compiled into the PROFILING build only (libmi_rast_prof.so, built by __graft_entry__.build(); the product library refuses
+    the flags).  A test that compares the product kernels with them calls this first: in the normal run it re-runs itself in a
+    subprocess with MI_RAST_LIB pointing at the profiling build (which holds the product kernels as well, compiled from the
+    same sources) and returns False -- nothing left to do --; inside that subprocess it returns True."""
+    import subprocess
+    import sys
+    if os.environ.get("MI_RAST_LIB") == PROF_LIB:
+        return True
+    assert os.path.exists(PROF_LIB), f"{PROF_LIB} missing: python -m seganygaussians_amd.build --profiling (or __graft_entry__.build())"
+    out = subprocess.run([sys.executable, "-m", "pytest", request.node.nodeid, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
+                         env=dict(os.environ, MI_RAST_LIB=PROF_LIB), capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert out.returncode == 0, "under the profiling library:\n" + out.stdout[-4000:] + out.stderr[-2000:]
+    return False
+
+
 def rank_camera(rank):
     """The pose bench.py gives rank `rank` of BASELINE config 4 (8 orbit poses over the same Gaussians; rank 0 = front view)."""
     return "front" if rank == 0 else ("orbit", 0.05 * rank, 0.02 * rank)
@@ -97,12 +119,12 @@ class GpuRun:
         self.with_mask = inp.mask is not None
 
     def forward(self, debug=False, full_lists=True, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None,
-                prezero=False):
+                prezero=False, exact_exp=None):
         """full_lists=True materialises the reference's point_list / full-list positions (what the bit-exact
         comparisons with the oracle read); False is the product default ("lean" lists, include/mi_rast.h)."""
         i = self.inp
         with self.R.forward_flags(full_lists=bool(full_lists), f32_blend=f32_blend, no_cull=no_cull, fast_exp=fast_exp,
-                                  verify_lists=verify_lists, tile_fwd=tile_fwd):
+                                  verify_lists=verify_lists, tile_fwd=tile_fwd, exact_exp=exact_exp):
             res = self.R.rasterize_gaussians_native(
                 i.channels, self.with_mask, self.bg, self.means3D, self.colors, self.opac, self.mask, self.scales,
                 self.rots, i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, i.image_height,

@@ -43,10 +43,10 @@ def test_get_higher_msb_matches_oracle_and_reference_cases(lib):
 
 
 def test_supported_channels(lib):
-    arr = (ctypes.c_int * 32)()
-    n = lib.mi_rast_supported_channels(arr, 32)
-    assert sorted(arr[:n]) == [3] + list(range(16, 257, 16))      # RGB, and channel blocks of 64 / 32 / 16 up to 256
-    assert lib.mi_rast_supported_channels(arr, 2) == n and list(arr[:2]) == [3, 16]
+    arr = (ctypes.c_int * 300)()
+    n = lib.mi_rast_supported_channels(arr, 300)
+    assert list(arr[:n]) == list(range(1, 257))      # any width up to 256 (channel blocks of 64 / 32 / 16, the last one possibly partial)
+    assert lib.mi_rast_supported_channels(arr, 2) == n and list(arr[:2]) == [1, 2]
 
 
 def test_layouts_are_aligned_and_disjoint(lib):

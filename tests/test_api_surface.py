@@ -68,3 +68,49 @@ def test_knn_dropin_names_and_no_cpu_fallback():
         distCUDA2(pts)
     with pytest.raises(RuntimeError, match="GPU tensor"):
         pytorch3d.ops.knn_points(pts[None], pts[None], K=3)
+
+
+def test_prezero_follows_the_callers_grad_mode(monkeypatch):
+    """The forward asks for the backward's accumulators to be zero-filled (prezero) only when a backward can follow: an input
+    requires grad AND the caller's grad mode is on.  `ctx.needs_input_grad` alone says requires_grad whatever the mode, so
+    render.py's `torch.no_grad()` forwards of a model whose parameters require grad would fill 128 MB per view for nothing."""
+    import diff_gaussian_rasterization_contrastive_f as cf
+    from seganygaussians_amd import rasterizer as R
+
+    seen = []
+
+    class Stop(Exception):
+        pass
+
+    def fake_native(*a, prezero=False, **k):
+        seen.append(bool(prezero))
+        raise Stop()
+
+    monkeypatch.setattr(R, "rasterize_gaussians_native", fake_native)
+    s = cf.GaussianRasterizationSettings(image_height=4, image_width=5, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(32),
+                                         scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0,
+                                         campos=torch.zeros(3), prefiltered=False, debug=False)
+    r = cf.GaussianRasterizer(raster_settings=s)
+    m = torch.zeros(2, 3)
+    feats = torch.zeros(2, 32, requires_grad=True)
+    kw = dict(means3D=m, means2D=m, opacities=m[:, :1], colors_precomp=feats, scales=m, rotations=torch.zeros(2, 4))
+    with pytest.raises(Stop):
+        r(**kw)
+    with torch.no_grad(), pytest.raises(Stop):
+        r(**kw)
+    with pytest.raises(Stop):
+        r(**dict(kw, colors_precomp=feats.detach()))
+    assert seen == [True, False, False]
+
+
+def test_channel_width_mismatches_are_refused():
+    """The width is a run-time argument here (the reference compiles NUM_CHANNELS in and indexes bg / colors unchecked): a
+    background with fewer entries than channels, or colours of another width than the call says, raise before anything runs."""
+    from seganygaussians_amd import rasterizer as R
+    m = torch.zeros(2, 3)
+    args = lambda ch, bg, col: (ch, False, bg, m, col, m[:, :1], None, m, torch.zeros(2, 4), 1.0, torch.empty(0), torch.eye(4),
+                                torch.eye(4), 1.0, 1.0, 4, 5, torch.empty(0), 0, torch.zeros(3), False, False)
+    with pytest.raises(RuntimeError, match="bg must hold one value per channel"):
+        R.rasterize_gaussians_native(*args(64, torch.zeros(32), torch.zeros(2, 64)))
+    with pytest.raises(RuntimeError, match=r"colors_precomp must have dimensions \(num_points, 32\)"):
+        R.rasterize_gaussians_native(*args(32, torch.zeros(32), torch.zeros(2, 64)))

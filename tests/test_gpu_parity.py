@@ -4,6 +4,7 @@ Bar: bit-exact on the integer tile/sort path; <= 1e-4 re
 and on every gradient.  Run on a real MI355X:  python -m pytest tests -m gpu -x -q
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -62,14 +63,18 @@ def test_features32_dense():
 
 
 @pytest.mark.parametrize("C", [32, 64])
-def test_features_forward_x3_matches_f32_mfma(C):
-    """The default 32 / 64-channel forward (blend_fwd_wave.h: one wave per quadrant) accumulates on the bf16 matrix pipe with
+def test_features_forward_x3_matches_f32_mfma(C, request):
+    """The 32 / 64-channel forward (blend_fwd_wave.h: one wave per quadrant) accumulates on the bf16 matrix pipe with
     exactly split operands; MI_RAST_TILE_FWD selects the tile-batched kernel with the same accumulation (blend_fwd_x3.h, round 2's
-    default), MI_RAST_F32_BLEND the f32-MFMA kernel (a bit-exact fmaf chain).  Same lists, same alpha / T / n_contrib and the same
-    per-tile walk counters (bit-identical), and images that differ by rounding of the f32 accumulation only (a few ulp; same
-    distance from the fp64-accumulating oracle)."""
+    default), MI_RAST_F32_BLEND the f32-MFMA kernel (a bit-exact fmaf chain).  With expf for every pair (MI_RAST_EXACT_EXP; the
+    other two kernels have no other form): same lists, same alpha / T / n_contrib and the same per-tile walk counters
+    (bit-identical), and images that differ by rounding of the f32 accumulation only (a few ulp; same distance from the
+    fp64-accumulating oracle).  The product default (hybrid exp, csrc/common.h) is judged against that in
+    test_hybrid_exp_takes_the_decisions_of_expf.  (The two comparison kernels live in the profiling build: helpers.py.)"""
+    if not hp.rerun_with_profiling_library(request):
+        return
     inp = hp.make_inputs(60_000, 640, 360, C, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
-    x3 = hp.GpuRun(inp).forward()
+    x3 = hp.GpuRun(inp).forward(exact_exp=True)
     f32 = hp.GpuRun(inp).forward(f32_blend=True)
     a, b = x3.color.cpu().numpy().astype(np.float64), f32.color.cpu().numpy().astype(np.float64)
     assert not np.array_equal(a, b), "expected two different kernels (is the switch still wired?)"
@@ -94,6 +99,53 @@ def test_features_forward_x3_matches_f32_mfma(C):
         np.testing.assert_array_equal(ia[k], ib[k], err_msg=k)
 
 
+@pytest.mark.parametrize("case", ["features32", "features64", "rgb", "depth", "faint"])
+def test_hybrid_exp_takes_the_decisions_of_expf(case):
+    """Product default of the wave-per-quadrant forward (csrc/common.h "HYBRID evaluation"): v_exp_f32(x log2e) away from the
+    alpha >= 1/255 cut, the device library's expf for every pair of entries in which some pixel comes within 4e-6 (relative) of
+    it.  Against MI_RAST_EXACT_EXP (expf everywhere = what a build of the reference's kernels computes): the image agrees to
+    3e-6 of its scale (measured: 1.3e-6), final_T to 3e-6 relative, and n_contrib -- the last entry each pixel blended -- on all but a handful of
+    pixels (T < 1e-4 stop decisions that sit within an ulp or two; no tolerance for the 1/255 decisions: a flipped one moves
+    n_contrib on its pixel AND the image there by ~0.4 %, which the bound on the image would catch)."""
+    if case == "features32":
+        inp = hp.make_inputs(60_000, 640, 360, 32, seed=3, focal=480.0, log_scale=math.log(0.03), log_scale_std=0.8)
+    elif case == "features64":
+        inp = hp.make_inputs(20_000, 320, 208, 64, seed=5, log_scale=math.log(0.04))
+    elif case == "rgb":
+        inp = hp.inputs_from_config("cfg1", with_shs=True)
+    elif case == "depth":
+        inp = hp.make_inputs(20_000, 480, 272, 3, seed=6, with_shs=True, sh_degree=3, use_mask=True, bg="random")
+    else:   # opacities scaled down: most pairs sit near the cut
+        inp = hp.make_inputs(30_000, 320, 208, 32, seed=9, log_scale=math.log(0.05))
+        inp.opacities = (np.asarray(inp.opacities) * 0.02).astype(np.float32)
+    hy = hp.GpuRun(inp).forward(full_lists=False)
+    ex = hp.GpuRun(inp).forward(full_lists=False, exact_exp=True)
+    a, b = hy.color.cpu().numpy().astype(np.float64), ex.color.cpu().numpy().astype(np.float64)
+    assert not np.array_equal(a, b), "expected two different evaluations (is the flag still wired?)"
+    scale = np.abs(b).max()
+    ih, ie = hy.img_fields(), ex.img_fields()
+    flipped = (ih["n_contrib"] != ie["n_contrib"]).reshape(inp.image_height, inp.image_width)
+    assert np.abs(a - b)[:, ~flipped].max() <= 3e-6 * scale, (np.abs(a - b)[:, ~flipped].max(), scale)
+    assert np.abs(a - b).max() <= 1e-3 * scale    # (one entry more or less at T ~ 1e-4)
+    # (a pixel whose T < 1e-4 stop fell the other way differs by one blended entry: counted with n_contrib below)
+    same = ih["n_contrib"] == ie["n_contrib"]
+    np.testing.assert_allclose(ih["final_T"][same], ie["final_T"][same], rtol=3e-6, atol=0)
+    nc = float((ih["n_contrib"] != ie["n_contrib"]).mean())
+    print(f"hybrid vs expf ({case}): image max diff {np.abs(a - b).max() / scale:.1e} of scale, n_contrib differs on {nc:.1e} of the pixels")
+    assert nc <= 2e-5, nc
+    for k in ("out_mask", "out_depth"):
+        if getattr(hy, k) is not None:
+            x, y = getattr(hy, k).cpu().numpy().astype(np.float64), getattr(ex, k).cpu().numpy().astype(np.float64)
+            assert np.abs(x - y)[:, ~flipped].max() <= 3e-6 * np.abs(y).max(), k
+    # the backward (expf) re-takes the forward's decisions: gradients of the two forwards agree far inside the 1e-4 contract
+    dL = scenes.make_grad_image(inp.channels, inp.image_height, inp.image_width, seed=1)
+    dLm = None if inp.mask is None else (np.random.default_rng(8).normal(0, 1, (1, inp.image_height, inp.image_width))
+                                         / (inp.image_width * inp.image_height)).astype(np.float32)
+    gh, ge = hy.backward(dL, dLm), ex.backward(dL, dLm)
+    for k, want in ge.items():
+        hp.assert_close(k + " (hybrid vs expf forward)", gh[k], want, rtol=2e-4, flip_frac=max(hp.GRAD_FLIP_FRAC, 1.5 / max(1, want.size)))
+
+
 def test_features32_odd_size_random_bg():
     """Image size not a multiple of 16: edge tiles with pixels outside the image (forward.cu:288-290,378)."""
     inp = hp.make_inputs(8_000, 203, 117, 32, seed=4, bg="random", camera="orbit")
@@ -106,11 +158,13 @@ def test_features64():
     _fwd_bwd(inp)
 
 
-@pytest.mark.parametrize("C", [16, 48, 80, 96, 112, 128, 256])
+@pytest.mark.parametrize("C", [16, 48, 80, 96, 112, 128, 256, 1, 2, 5, 8, 15, 17, 40, 50, 100, 255])
 def test_feature_widths_in_channel_blocks(C):
-    """Any multiple of 16 channels up to 256 (the reference: any compile-time NUM_CHANNELS): blended in channel blocks of
-    64 / 32 / 16, e.g. 112 = 64 + 32 + 16 -- image, every gradient (the geometry gradients are sums over the blocks), lean == full,
-    against the oracle; random background so that the background term of dL/dalpha is split over the blocks as well."""
+    """Any width up to 256 (the reference: any compile-time NUM_CHANNELS): blended in channel blocks of 64 / 32 / 16, e.g.
+    112 = 64 + 32 + 16, the last block partial when the width is no multiple of 16 (17 = 16 + 1 of 16; 50 = 32 + 16 + 2 of 16, with
+    rows that are not 16-byte aligned; 255 = 3 x 64 + 32 + 16 + 15 of 16) -- image, every gradient (the geometry gradients are sums
+    over the blocks), lean == full, against the oracle; random background so that the background term of dL/dalpha is split over
+    the blocks as well.  (3 channels with precomputed colours take the RGB kernels: test_rgb_* above.)"""
     _fwd_bwd(hp.make_inputs(6000, 208, 144, C, seed=50 + C, log_scale=math.log(0.05), bg="random", camera="orbit"))
 
 
@@ -119,11 +173,17 @@ def test_unsupported_channel_counts_fail_loudly():
     from seganygaussians_amd import rasterizer as R
     inp = hp.make_inputs(10, 32, 32, 3, seed=1)
     g = hp.GpuRun(inp)
-    for C in (8, 40, 272):
+    for C in (257, 272):   # (0 channels: refused by the glue's shape checks before the library sees it)
         with pytest.raises(RuntimeError, match="unsupported channel count"):
             R.rasterize_gaussians_native(C, False, torch.zeros(C, device="cuda"), g.means3D, torch.zeros(10, C, device="cuda"), g.opac,
                                          None, g.scales, g.rots, 1.0, g.cov, g.view, g.proj, inp.tanfovx, inp.tanfovy, 32, 32,
                                          g.shs, 0, g.campos, False, False)
+    # the comparison kernels of earlier rounds are no part of the product library
+    if os.environ.get("MI_RAST_LIB") != hp.PROF_LIB:
+        inp32 = hp.make_inputs(10, 32, 32, 32, seed=1)
+        for kw in (dict(tile_fwd=True), dict(f32_blend=True)):
+            with pytest.raises(RuntimeError, match="comparison kernels of the profiling build"):
+                hp.GpuRun(inp32).forward(**kw)
 
 
 def test_depth_variant_with_mask():
@@ -295,12 +355,14 @@ def test_long_tile_lists_all_sort_classes():
 
 
 @pytest.mark.parametrize("case", ["rgb", "features32", "depth"])
-def test_cull_is_exactly_conservative(case):
+def test_cull_is_exactly_conservative(case, request):
     """MI_RAST_NO_CULL hands EVERY overlap of the reference's tile lists to the blend kernels (all four quadrant bits).  The
     exact-conservative cull may only ever drop pairs that cannot reach alpha >= 1/255 anywhere in their quadrant, so the
     image, final_T, n_contrib, mask and depth must be BIT-IDENTICAL with and without it (a wrongly culled pair at
     alpha ~ 1/255 would move a pixel by ~0.4 %: no tolerance could tell that from a threshold flip), the integer path is
     untouched, and the gradients agree up to the order of the atomic sums."""
+    if case == "features32" and not hp.rerun_with_profiling_library(request):   # (uses the f32-chain forward: profiling build)
+        return
     if case == "rgb":
         inp = hp.inputs_from_config("cfg1", with_shs=True)
     elif case == "features32":
@@ -310,8 +372,9 @@ def test_cull_is_exactly_conservative(case):
     # 32 channels: the f32 FMA-chain forward adds the pairs one by one in list order, so pairs with weight 0 change no bit; the
     # default bf16x3 forward sums 16 pairs per matrix instruction, and extra zero-weight pairs regroup its partial sums (ulps)
     f32 = True if inp.channels == 32 else None
-    on = hp.GpuRun(inp).forward(f32_blend=f32)
-    off = hp.GpuRun(inp).forward(no_cull=True, f32_blend=f32)
+    # (expf for every pair: the hybrid form falls back to expf per PAIR of queued entries, and without the cull the pairs differ)
+    on = hp.GpuRun(inp).forward(f32_blend=f32, exact_exp=True)
+    off = hp.GpuRun(inp).forward(no_cull=True, f32_blend=f32, exact_exp=True)
     assert off.num_rendered == on.num_rendered
     if f32:
         a, b = hp.GpuRun(inp).forward().color, hp.GpuRun(inp).forward(no_cull=True).color
@@ -335,15 +398,15 @@ def test_cull_is_exactly_conservative(case):
         hp.assert_close(k + " (cull off vs on)", g_off[k], want, rtol=2e-4, flip_frac=max(hp.GRAD_FLIP_FRAC, 1.5 / max(1, want.size)))
 
 
-@pytest.mark.parametrize("C,kw", [(3, {}), (3, {"use_mask": True}), (32, {}), (48, {}), (64, {}), (16, {}), (32, {"tile_fwd": True}),
+@pytest.mark.parametrize("C,kw", [(3, {}), (3, {"use_mask": True}), (32, {}), (48, {}), (64, {}), (16, {}), (40, {}),
                                   (32, {"P": 60_000, "W": 64, "H": 48})])
 def test_forward_prefills_the_backward_accumulators(C, kw):
     """include/mi_rast.h dL_dcolor_next / MI_RAST_PREZERO_BWD: the forward's blend kernel leaves the backward's accumulators --
     the (P, channels) dL_dcolor buffer and the packed field gradients + work-queue counters in the geometry buffer -- zero-filled
     (what torch::zeros does in CF/rasterize_points.cu:153-159), and the backward then skips its fills.  Checked with NaN /
     0xFF left in the allocator's free blocks, for the wave-per-quadrant kernels (RGB, RGB + mask + depth, 32, 64, 48 = 32 + 16:
-    the first block's launch takes the fill), for kernels that do not take it (16 channels; the tile-batched forward: fill
-    commands), with an odd P (the (P, 3) buffer is not a whole number of 16-byte units), and with more zeros than image (60 000
+    the first block's launch takes the fill), for kernels that do not take it (16 channels: fill commands), for a width
+    whose (P, C) block the partial last block shares (40 = 32 + 8 of 16), with an odd P (the (P, 3) buffer is not a whole number of 16-byte units), and with more zeros than image (60 000
     Gaussians on 64 x 48 pixels: the kernel takes the fill only while it at most doubles its own stores).  Gradients equal those of a plain run."""
     import torch
     from seganygaussians_amd import _lib

@@ -49,6 +49,13 @@ def _pin_oracle(inp, variant=None):
     return rep, ref, rf, rb
 
 
+# The product's forward evaluates exp() in the hybrid form of csrc/common.h: every alpha >= 1/255 decision is expf's, i.e. the
+# reference build's; alpha itself differs by <= 1e-6 relative, so T does too, and a T < 1e-4 stop decision that sits within an
+# ulp or two can fall the other way: n_contrib may differ from the reference's on a few pixels in a million.  With
+# MI_RAST_EXACT_EXP it is equal on every pixel (test_full_size_cfg3_product_vs_ref_and_oracle checks both).
+NC_MISMATCH_HYBRID = 5e-6
+
+
 def _product_vs_ref(inp, variant=None, lean=True, fast_exp=None):
     """product (full-list mode for the integer path) vs reference; then the product default (lean lists) vs full."""
     ref = sr.RefRun(inp, variant)
@@ -67,7 +74,7 @@ def _product_vs_ref(inp, variant=None, lean=True, fast_exp=None):
 
 
 def test_reference_libraries_present():
-    for v in ("cf32", "cf32_fast", "cf64", "cf16", "cf128", "base3", "depth3", "knn"):
+    for v in ("cf32", "cf32_fast", "cf64", "cf16", "cf128", "cf8", "cf40", "cf100", "base3", "depth3", "knn"):
         assert sr.available(v), f"oracle/_ref/libsaga_ref_{v}.so missing: run python oracle/build_ref.py in the build container"
     assert sr.lib("cf32").saga_ref_channels() == 32 and sr.lib("cf64").saga_ref_channels() == 64
     assert sr.lib("base3").saga_ref_channels() == 3 and sr.lib("depth3").saga_ref_is_depth() == 1
@@ -191,25 +198,61 @@ def test_product_vs_ref_reduced_cfg3_cfg2_cfg5():
     _product_vs_ref(hp.make_inputs(20_000, 320, 208, 64, seed=5, log_scale=math.log(0.04)))
 
 
-@pytest.mark.parametrize("C", [16, 128])
+@pytest.mark.parametrize("C", [16, 128, 8, 40, 100])
 def test_product_vs_ref_channel_blocks(C):
     """Feature widths other than 32 / 64: the product blends them in channel blocks of 64 / 32 / 16 (mi_rast.hip:
-    channels_supported) -- against reference builds with NUM_CHANNELS = 16 and 128, fwd + bwd, lean == full."""
+    channels_supported), the last one partial when the width is no multiple of 16 (8 = 8 of 16, 40 = 32 + 8 of 16,
+    100 = 64 + 32 + 4 of 16) -- against reference builds with those NUM_CHANNELS, fwd + bwd, lean == full."""
     _product_vs_ref(hp.make_inputs(12_000, 320, 208, C, seed=30 + C, log_scale=math.log(0.04), bg="random"))
     _product_vs_ref(hp.make_inputs(4_000, 203, 117, C, seed=40 + C, camera="orbit"))
 
 
 # The norm-wise error of dL_dcov3D / dL_dscales / dL_drotations hangs on a handful of cancellation-prone rows of the (shared,
 # binary32) per-Gaussian geometry backward and moves by 2-4x from run to run in BOTH implementations -- the order of the f32
-# atomics that feed it is not deterministic.  Observed for the REFERENCE itself against the exact-pairs oracle over the cfg3 / cfg4
-# / cfg5 runs of round 3 (gpurun_out/r3_*): cov3D 8.1e-6 .. 8.2e-5, scales 1.2e-5 .. 6.7e-5, rotations 3.3e-5 .. 1.3e-4.  A bound
-# of 4x ONE draw of the reference is therefore a coin toss for these three; they are bounded by 4x the larger of that draw and the
-# top of the reference's observed range, and judged on the stable statistic (rows outside tolerance) like every other tensor.
-REF_NORM_SWING = {"dL_dcov3D": 8.2e-5, "dL_dscales": 6.7e-5, "dL_drotations": 1.3e-4}
+# atomics that feed it is not deterministic (observed for the REFERENCE itself against the exact-pairs oracle in round 3: cov3D
+# 8.1e-6 .. 8.2e-5, scales 1.2e-5 .. 6.7e-5, rotations 3.3e-5 .. 1.3e-4).  One draw of each side is therefore a coin toss for
+# these three.  They are judged on DRAWS taken inside the test: the backward of the reference and of the product are each run
+# SWING_DRAWS times on the same forward, and the product's MEDIAN norm-wise error must stay within 2x the reference's LARGEST
+# (round 3 bounded them by constants copied from earlier runs instead).  Every other tensor is stable (measured ratios 0.9 .. 1.1)
+# and keeps the 4x-of-this-run bound; all of them are also judged on the stable statistic, rows outside tolerance.
+SWING = ("dL_dcov3D", "dL_dscales", "dL_drotations")
+SWING_DRAWS = 3
 
 
 def _norm_bound(k, ref_norm, factor=4.0):
-    return factor * max(ref_norm, REF_NORM_SWING.get(k, 0.0)) + 1e-7
+    return factor * ref_norm + 1e-7
+
+
+def _swing_draws(gpu, ref, dL, dLm, ob, mine, theirs):
+    """{tensor: (product's median, reference's max)} of the norm-wise error against `ob` over SWING_DRAWS backward runs each
+    (the draws already in `mine` / `theirs` count as the first)."""
+    prod = {k: [mine[k]["norm"]] for k in SWING if k in mine}
+    refd = {k: [theirs[k]["norm"]] for k in prod}
+    for _ in range(SWING_DRAWS - 1):
+        g = hp.error_stats(gpu.backward(dL, dLm), ob, names=SWING)
+        r = hp.error_stats(hp.grads_as_dict(ref.backward(dL, dLm)), ob, names=SWING)
+        for k in prod:
+            prod[k].append(g[k]["norm"])
+            refd[k].append(r[k]["norm"])
+    return {k: (float(np.median(prod[k])), float(max(refd[k]))) for k in prod}
+
+
+def _judge_against_reference(what, mine, theirs, swing):
+    bad = []
+    for k, s in mine.items():
+        r = theirs[k]
+        print(f"{what} {k}: norm {s['norm']:.2e} rows outside {s['row_frac']:.2e} worst {s['row_worst']:.1f}"
+              f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}")
+        assert not s["zero_rows_touched"]
+        if k in swing:
+            med, ref_max = swing[k]
+            print(f"{what} {k}: over {SWING_DRAWS} draws each, product median {med:.2e}, reference max {ref_max:.2e}")
+            norm_ok = med <= 2 * ref_max + 1e-7
+        else:
+            norm_ok = s["norm"] <= _norm_bound(k, r["norm"])
+        if not (norm_ok and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
+            bad.append((k, s, r, swing.get(k)))
+    assert not bad, bad
 
 
 def _check_stats(stats, ref_stats, what, row_floor=1e-3, norm_floor=1e-4):
@@ -248,7 +291,8 @@ def _cfg3_stats(fast_exp):
     print(f"cfg3 image norm-wise error against the fp64 oracle: product {img_norm:.2e}, reference {ref_norm:.2e}")
     nc_mismatch = float((gpu.img_fields()["n_contrib"] != rf.state.field(so.F_N_CONTRIB)).mean())
     print(f"cfg3: n_contrib differs from the reference on {nc_mismatch:.2e} of the pixels")
-    return mine, theirs, img_norm, ref_norm, nc_mismatch
+    swing = {} if fast_exp else _swing_draws(gpu, ref, dL, None, ob, mine, theirs)
+    return mine, theirs, img_norm, ref_norm, nc_mismatch, swing
 
 
 def test_full_size_cfg3_product_vs_ref_and_oracle():
@@ -256,32 +300,31 @@ def test_full_size_cfg3_product_vs_ref_and_oracle():
     image, final_T, all gradients; lean == full), with norm-wise and per-row (median floor) error statistics measured
     against the oracle for BOTH the product and the reference.  The yardstick evaluates every per-pair value AND every sum in
     binary64 (so.backward(exact_pairs=True)); the default oracle mode rounds per-pair values like the reference's kernel, which
-    hides that part of the reference's error (~2.4e-7 norm-wise) and counts it against everybody else.  The product calls the
-    device library's expf like the reference's kernels (FEAT/forward.cu:343, backward.cu:483), so every alpha >= 1/255 and
-    T < 1e-4 decision falls as in the reference: the per-pixel contributor counts are EQUAL on every pixel, and the product's
-    gradient errors are those of the reference itself (measured ratios 0.9 .. 1.1; the figures of dL_dcov3D / scales /
+    hides that part of the reference's error (~2.4e-7 norm-wise) and counts it against everybody else.  The product takes
+    every alpha >= 1/255 decision with the device library's expf like the reference's kernels (FEAT/forward.cu:343,
+    backward.cu:483; forward: the hybrid form of csrc/common.h), so the same pairs blend as in the reference; the per-pixel
+    contributor counts agree on all but a few pixels in a million (T < 1e-4 stops within an ulp or two; EQUAL on every pixel
+    under MI_RAST_EXACT_EXP, checked at the end), and the product's gradient errors are those of the reference itself (measured ratios 0.9 .. 1.1; the figures of dL_dcov3D / scales /
     rotations hang on a few cancellation-prone rows and move by 2x from run to run in BOTH implementations, the order of f32
-    atomics not being deterministic) -- asserted at 2x (rows outside tolerance) / 4x (norm-wise)."""
-    mine, theirs, img_norm, ref_norm, nc_mismatch = _cfg3_stats(fast_exp=None)
-    bad = []
-    for k, s in mine.items():
-        r = theirs[k]
-        print(f"cfg3 {k}: norm {s['norm']:.2e} rows outside {s['row_frac']:.2e} worst {s['row_worst']:.1f}"
-              f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}")
-        assert not s["zero_rows_touched"]
-        # (4x norm-wise -- REF_NORM_SWING above for the three tensors whose figure swings run to run --, 2x on the row count)
-        if not (s["norm"] <= _norm_bound(k, r["norm"]) and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
-            bad.append((k, s, r))
-    assert not bad, bad
-    assert nc_mismatch == 0.0
+    atomics not being deterministic) -- asserted at 2x (rows outside tolerance) / 4x (norm-wise; the three swinging tensors on draws, see SWING)."""
+    mine, theirs, img_norm, ref_norm, nc_mismatch, swing = _cfg3_stats(fast_exp=None)
+    # 4x norm-wise of this run's reference draw (the three swinging tensors: product's median of SWING_DRAWS draws within 2x the
+    # reference's largest, see SWING above), 2x on the row count
+    _judge_against_reference("cfg3", mine, theirs, swing)
+    assert nc_mismatch <= NC_MISMATCH_HYBRID
     assert img_norm <= max(1e-6, 3 * ref_norm)
+    # expf for every pair: every decision falls as in the reference build -- the per-pixel contributor counts are EQUAL everywhere
+    inp = hp.inputs_from_config("cfg3")
+    ex = hp.GpuRun(inp).forward(exact_exp=True)
+    rf = sr.RefRun(inp, None).forward()
+    assert float((ex.img_fields()["n_contrib"] != rf.state.field(so.F_N_CONTRIB)).mean()) == 0.0
 
 
 def test_full_size_cfg3_fast_exp_mode():
     """MI_RAST_FAST_EXP (include/mi_rast.h): v_exp_f32(x * log2e), ~5 ulp.  A handful of pairs within a few ulp of the
     alpha >= 1/255 cut change side; still inside the contract (1e-4 element-wise, checked by _product_vs_ref) and within
     3x the reference's own norm-wise / per-row noise (floors 1e-4 / 1e-3)."""
-    mine, theirs, img_norm, ref_norm, nc_mismatch = _cfg3_stats(fast_exp=True)
+    mine, theirs, img_norm, ref_norm, nc_mismatch, _ = _cfg3_stats(fast_exp=True)
     _check_stats(mine, theirs, "cfg3 fast-exp product-vs-oracle")
     assert nc_mismatch < 1e-4
     assert img_norm <= max(1e-5, 3 * ref_norm)
@@ -308,23 +351,15 @@ def _assert_like_reference(inp, what):
     reference each against the fp64-accumulating oracle on the same input: the product's norm-wise error must stay within 4x
     and its rows outside tolerance within 2x of the reference's own f32-atomic noise; n_contrib equal on every pixel."""
     rep, gpu, ref, rf, rb, grads = _product_vs_ref(inp)
-    dL, _ = _dL(inp)
+    dL, dLm = _dL(inp)
     of = so.forward(inp)
     ob = so.backward(inp, of, dL, exact_pairs=True)   # binary64 per-pair values: a yardstick that shares nobody's rounding
     mine = hp.error_stats(grads, ob)
     theirs = hp.error_stats(hp.grads_as_dict(rb), ob)
     nc_mismatch = float((gpu.img_fields()["n_contrib"] != rf.state.field(so.F_N_CONTRIB)).mean())
     print(f"{what}: R = {rf.num_rendered}, n_contrib differs from the reference on {nc_mismatch:.2e} of the pixels")
-    bad = []
-    for k, s in mine.items():
-        r = theirs[k]
-        print(f"{what} {k}: norm {s['norm']:.2e} rows outside {s['row_frac']:.2e} worst {s['row_worst']:.1f}"
-              f" | reference's own: norm {r['norm']:.2e} rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}")
-        assert not s["zero_rows_touched"]
-        if not (s["norm"] <= _norm_bound(k, r["norm"]) and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
-            bad.append((k, s, r))
-    assert not bad, bad
-    assert nc_mismatch == 0.0
+    _judge_against_reference(what, mine, theirs, _swing_draws(gpu, ref, dL, dLm, ob, mine, theirs))
+    assert nc_mismatch <= NC_MISMATCH_HYBRID
     return rf
 
 

@@ -5,7 +5,7 @@ for rep in 1 2; do
 for v in $1; do
   lib=$PWD/seganygaussians_amd/libmi_rast_$v.so
   [ "$v" = "default" ] && lib=$PWD/seganygaussians_amd/libmi_rast.so
-  MI_RAST_LIB=$lib python bench.py --no-cpu-baseline --steps 40 --warmup 5 --settle 1 ${2:-} 2>/dev/null | tail -1 | python -c "
+  MI_RAST_LIB=$lib python bench.py --no-cpu-baseline --steps 40 --warmup 5 --settle 1 --sustained-seconds 0 ${2:-} 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('variant $v', d['value'], d['ms_per_step'], d['config']['stages_ms'])"

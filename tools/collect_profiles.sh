@@ -11,7 +11,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG$SFX
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --config $CFG --steps 10 --warmup 2 --settle 0 --dist-blocks 0 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --config $CFG --steps 10 --warmup 2 --settle 0 --dist-blocks 0 --sustained-seconds 0 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
 tail -1 $OUT/trace.log > $OUT/bench_line_profiled.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "mirast" --output-format csv -d $OUT -o fetch -- $BENCH > $OUT/fetch.log 2>&1
