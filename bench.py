@@ -264,8 +264,9 @@ def main():
         torch.autograd.backward(color, grad_tensors=dL)
         if host_trace is not None:   # MI_BENCH_HOST_TRACE: host time of the two calls of every step (no extra syncs)
             host_trace.append((t_a, t_b, time.perf_counter()))
-        if dist is not None:
+        if dist is not None and not state.get("solo"):
             # sum the per-Gaussian feature gradients of the N views over RCCL/xGMI: one flat 128-MB bucket, asynchronous
+            # (not in rank 0's reporting-only steps behind the timed regions: a collective only one rank enters never completes)
             state["pending"] = allreduce_grads_async([feats.grad])
         state.update(radii=radii, color=color.detach(), means2D=means2D)
 
@@ -403,9 +404,11 @@ def main():
     roofline = None
     stages_ms = {}
     counters = {}
+    # From here to the --dump-grads step only rank 0 works (per-stage timing, counters, parity): its steps must not enter collectives
+    # the other ranks never join -- they wait for rank 0 in the dump step's all-reduce / in destroy_process_group.  (Until round 4 these
+    # steps did start the gradient all-reduce: harmless on the one-rank group of --dist-single, a deadlock with a real second rank.)
+    state["solo"] = True
     if rank == 0:
-        if dist is not None:
-            state.pop("pending", None)
         _lib.profile_enable(True)
         acc = {k: 0.0 for k in _lib.MI_STAGES}
         nprof = max(3, min(10, args.steps))
@@ -595,6 +598,7 @@ def main():
         if ref_on_gpu:
             out["reference_on_gpu"] = ref_on_gpu
     phase("reporting")
+    state["solo"] = False
     if args.dump_grads and not fwd_only:
         step()
         barrier()   # waits for this step's all-reduce: feats.grad now holds the sum over the ranks' views

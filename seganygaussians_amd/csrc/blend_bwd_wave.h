@@ -43,6 +43,13 @@ namespace mirast {
 #ifndef MI_BWD_SEPMOM
 #define MI_BWD_SEPMOM 0
 #endif
+// MI_BWD_DEFER (round 4, A/B): the feature-gradient atomics of a full chunk are not issued in one burst behind its contractions but
+// spread over the NEXT chunk's scalar recurrences (one 16-row group of atomics behind every four rows), the chunk's dF block
+// waiting in registers (C / 4 VGPRs) and its Gaussian ids in LDS.  The waves of a CU run chunks of identical length; issued at the
+// chunk's end, their atomics arrive at the L2 atomic units (20 G segment-requests/s, tools/atomic_limit_probe.hip) in convoys.
+#ifndef MI_BWD_DEFER
+#define MI_BWD_DEFER 0
+#endif
 // 1 / x to ~0.5 ulp: v_rcp_f32 (1 ulp) plus one Newton step (two FMAs).  T is divided by (1 - alpha) once per row and the
 // quotients are chained through the whole list: the reference uses a correctly rounded division there (backward.cu:487).
 #ifndef MI_BWD_RCP_REFINE
@@ -104,11 +111,13 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     __shared__ float4 s_feat4_[WPB][FEAT4];        // the chunk's 16 feature rows
     __shared__ float4 s_wu4_[WPB][2 * CHK * WROW / 4];  // S / w rows | u rows   (prologue: gradient-image staging; after step 3: moments)
     __shared__ uint2 s_queue_[WPB][QCAP];
+    __shared__ uint32_t s_pgid_[WPB][MI_BWD_DEFER ? CHK : 1];   // MI_BWD_DEFER: Gaussian ids of the chunk whose dF atomics are pending
     const int wv = WPB == 1 ? 0 : (int)(threadIdx.x >> 6);
     BwdPar* const s_par = s_par_[wv];
     float4* const s_feat4 = s_feat4_[wv];
     float4* const s_wu4 = s_wu4_[wv];
     uint2* const s_queue = s_queue_[wv];
+    uint32_t* const s_pgid = s_pgid_[wv];
 
     // One (tile, quadrant) item: everything below.  With one wave per workgroup (the product) a wave works through items it
     // takes from the queue of the XCD it runs on (see the end of the kernel).
@@ -307,8 +316,36 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     // path issues behind their loads; with the first chunk peeled off, every path into the loop's copy has issued the
     // previous chunk's atomics (a fixed number) behind them, so the wait leaves those in flight.
     int nnext = 0;
-    auto do_chunk = [&](auto full_tag) __attribute__((always_inline)) {
+    // MI_BWD_DEFER: dF block of the previous full chunk (lane (n16, kq): channel 16 nb + n16 of rows 4 kq + r), not yet added
+    v4f pend[NB];
+    bool have_pend = false;   // wave-uniform
+    // (`sure`: the caller knows a block is pending -- every chunk of the loop below; a run-time test there would let hipcc
+    // compute the vmcnt wait for the staged rows from the path WITHOUT these atomics, i.e. wait for them)
+    auto flush_pend = [&](const int r, const bool sure) __attribute__((always_inline)) {   // rows 4 kq + r of the pending chunk
+        if constexpr (MI_BWD_DEFER) {
+            if (sure || have_pend) {
+                const uint32_t gid = s_pgid[4 * kq + r];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const int ch = 16 * nb + n16;
+                    if constexpr (CR == C) {
+                        atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], pend[nb][r]);
+                    } else {
+                        if (ch < cr) atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], pend[nb][r]);
+                        else if (MASKGRAD && ch == CR) atomicAdd(&gpack[(size_t)gid * 8 + 6], pend[nb][r]);
+                    }
+                }
+            }
+        }
+    };
+    auto do_chunk = [&](auto full_tag, auto pend_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;   // all 16 rows are real: no padding, unconditional atomics
+        constexpr bool PEND = decltype(pend_tag)::value;   // MI_BWD_DEFER: the previous chunk's dF block is pending (FULL chunks)
+        if constexpr (MI_BWD_DEFER && !FULL) {   // the wave's last chunk: nothing to hide the pending atomics behind
+#pragma unroll
+            for (int r = 0; r < 4; r++) flush_pend(r, false);
+            have_pend = false;
+        }
         // ---- 1. the chunk's rows: registers -> LDS.  Rows beyond nrows (the wave's last chunk only) become padding
         // records: never valid (position 0x7ffffff), zero features, opacity 1; their atomics are masked off (adding their
         // exact zeros to some real row instead costs dearly: same-address atomics serialise at ~22 ns each).
@@ -464,7 +501,20 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             }
         };
         if constexpr (FULL) {  // straight-line code for the full chunk: the 16 rows' LDS reads overlap each other's arithmetic
-            if (has_bg) {
+            if constexpr (PEND) {
+                // (the pending atomics at the JOIN of the two forms of a four-row group: inside the arms, hipcc's structurizer leaves
+                // a path around one arm -- exec == 0, never taken -- and the vmcnt wait for the staged rows is computed from it)
+#pragma unroll
+                for (int r0 = 0; r0 < CHK; r0 += 4) {
+                    if (has_bg) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) row_step(r0 + k);
+                    } else {
+                        row_group4(r0);
+                    }
+                    flush_pend(r0 >> 2, true);
+                }
+            } else if (has_bg) {
 #pragma unroll
                 for (int rr = 0; rr < CHK; rr++) row_step(rr);
             } else {
@@ -534,8 +584,15 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
         // unconditionally (see the header): rows that contributed nothing add exact zeros.
         const BwdPar mine = *reinterpret_cast<const BwdPar*>(par_bytes + n16 * (int)sizeof(BwdPar));  // lane n16 = row n16
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the MFMA operand reads of the w rows are done: moments may land there
+        constexpr bool DEFER = MI_BWD_DEFER && FULL;
+        if constexpr (DEFER) {   // the next chunk adds this block (or the flush behind the last chunk does)
+            if (lane < CHK) s_pgid[lane] = __float_as_uint(mine.q1.w);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+            for (int nb = 0; nb < NB; nb++) pend[nb] = facc[nb];
+            have_pend = true;
+        }
+#pragma unroll
+        for (int r = 0; r < (DEFER ? 0 : 4); r++) {
             const int row = 4 * kq + r;
             // the row's Gaussian id, straight from the staged record (a __shfl would keep its lane arithmetic alive
             // across the whole kernel -- and spilled)
@@ -644,16 +701,39 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     // Full chunks: the first one peeled off, the rest in a loop whose every iteration issues the same memory instructions.
     // The wave's last, partial chunk runs a third copy with padding rows and predicated atomics (nothing is staged behind it).
     if (nrows == CHK) {
-        do_chunk(std::true_type{});
-        while (nnext == CHK) {
-            nrows = nnext;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // moment reads before the next chunk's S rows land there
-            do_chunk(std::true_type{});
+        do_chunk(std::true_type{}, std::false_type{});
+        if constexpr (MI_BWD_DEFER) {
+            // the second chunk peeled off as well, the loop INSIDE its branch: only then has every path into the loop's copy issued
+            // the same memory instructions (8 deferred feature atomics + 2 geometry atomics) behind the staged rows' loads, and the
+            // wait for those rows leaves all ten in flight (reachable from the first chunk -- 2 atomics behind its loads -- hipcc
+            // emits vmcnt(4) at the loop head: six atomics drained per chunk)
+            if (nnext == CHK) {
+                nrows = nnext;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                do_chunk(std::true_type{}, std::true_type{});
+                while (nnext == CHK) {
+                    nrows = nnext;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    do_chunk(std::true_type{}, std::true_type{});
+                }
+            }
+        } else {
+            while (nnext == CHK) {
+                nrows = nnext;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // moment reads before the next chunk's S rows land there
+                do_chunk(std::true_type{}, std::false_type{});
+            }
         }
         nrows = nnext;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    if (nrows != 0) do_chunk(std::false_type{});
+    if (nrows != 0) do_chunk(std::false_type{}, std::false_type{});
+    if constexpr (MI_BWD_DEFER) {
+        if (have_pend) {   // no partial chunk behind the last full one
+#pragma unroll
+            for (int r = 0; r < 4; r++) flush_pend(r, false);
+        }
+    }
     if (prof && lane == 0) {
         for (int i = 0; i < 9; i++) atomicAdd(&gpack[8 * (i + 1) + 7], (float)tk[i]);
         atomicAdd(&gpack[8 * 10 + 7], (float)n_chunks);

@@ -68,6 +68,16 @@ __device__ __forceinline__ void fwd_zero_fill(const FwdZeroFill& z, uint32_t wg,
 #ifndef MI_FWD_WAVES64
 #define MI_FWD_WAVES64 3
 #endif
+// A/B switches of the 32/64-channel kernel's group loop (round 4):
+#ifndef MI_FWD_PF2
+#define MI_FWD_PF2 1          // 1 (product): the rows of a group are requested TWO groups ahead (two register sets) instead of one
+#endif
+#ifndef MI_FWD_LIVE_EVERY
+#define MI_FWD_LIVE_EVERY 1   // the wave-uniform "every pixel is done" test (a branch) in front of every k-th pair of entries; 8: none
+#endif
+#ifndef MI_FWD_SB
+#define MI_FWD_SB 1           // scheduling barrier behind every pair of entries
+#endif
 
 // XM: how opacity * exp(power) is evaluated (common.h: ExpMode) -- EXP_HYBRID is the product default.
 template <int C, int XM = EXP_HYBRID, bool STRIDED = false>
@@ -139,36 +149,40 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
         scan_reg = reinterpret_cast<const uint2*>(rec + min(scanned + lane, ns - 1))[1];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
-    // Requests the rows queue[qh .. qh + n), n >= 1, of the next group: record quarter (lane & 3) of row (lane >> 2) and the
-    // feature parts.  Every lane loads (rows >= n repeat row n - 1 and are replaced by padding when the group is staged).
-    uint2 curq;
-    float4 featpf[NK];
-    auto request_rows = [&](int n) {
+    // Requests the rows queue[qh + ahead .. qh + ahead + n), n >= 1, of a coming group into one of the two register sets: record
+    // quarter (lane & 3) of row (lane >> 2) and the feature parts.  Every lane loads (rows >= n repeat row n - 1 and are replaced
+    // by padding when the group is staged).
+    struct RowRegs {
+        uint2 q;
+        float4 f[NK];
+    };
+    RowRegs setA, setB;
+    auto request_rows = [&](RowRegs& rr, int ahead, int n) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
             const int rq = min(lane >> 2, n - 1), qq = lane & 3;
-            const uint32_t j = s_queue[(qh + rq) & (QCAP - 1)].x;
-            curq = reinterpret_cast<const uint2*>(rec + j)[qq];
+            const uint32_t j = s_queue[(qh + ahead + rq) & (QCAP - 1)].x;
+            rr.q = reinterpret_cast<const uint2*>(rec + j)[qq];
         }
 #pragma unroll
         for (int k = 0; k < NK; k++) {
             const int e = lane + 64 * k;
             const int g = min(e / F4, n - 1), part = e % F4;
-            const size_t gid = (size_t)s_queue[(qh + g) & (QCAP - 1)].y;
-            featpf[k] = reinterpret_cast<const float4*>(features + gid * (size_t)cstride)[part];
+            const size_t gid = (size_t)s_queue[(qh + ahead + g) & (QCAP - 1)].y;
+            rr.f[k] = reinterpret_cast<const float4*>(features + gid * (size_t)cstride)[part];
         }
     };
 
-    while (qt - qh < XG && scanned < ns) consume_scan();
-    int n = min(XG, qt - qh);
-    if (n > 0) request_rows(n);
-    uint64_t live = ballot64(!done);  // lanes still blending (wave-uniform copy of !done)
+    uint64_t live = 0;  // lanes still blending (wave-uniform copy of !done)
     bool finished = false;
 
-    while (n > 0 && !finished) {
+    // One group of up to 16 entries whose rows wait in `rr`; `n_ahead` rows of the group behind it are in flight in the other
+    // register set (MI_FWD_PF2) or none (n_ahead = 0).  Requests the group behind those into `rr` and returns its row count.
+    auto do_group = [&](RowRegs& rr, const int n, const int n_ahead) __attribute__((always_inline)) -> int {
         // ---- 1. the group's rows: registers -> LDS.  Rows beyond n (the wave's last group only) become padding: opacity 0
         // (never blends) and zero features.
         {
+            const uint2 curq = rr.q;
             const int rq = lane >> 2, qq = lane & 3;
             // quarter 0 = {x, y}; 1 = {id, pm} -> {position + 1, pm}; 2 = {a, b} -> {-a/2, -b}; 3 = {c, opacity} -> {-c/2, opacity}
             float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
@@ -189,8 +203,8 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
                 const int g = e / F4, part = e % F4;
                 uint2 hi = make_uint2(0u, 0u), mid = hi, lo = hi;
                 if (g < n) {
-                    split3_bf16x2(featpf[k].x, featpf[k].y, hi.x, mid.x, lo.x);
-                    split3_bf16x2(featpf[k].z, featpf[k].w, hi.y, mid.y, lo.y);
+                    split3_bf16x2(rr.f[k].x, rr.f[k].y, hi.x, mid.x, lo.x);
+                    split3_bf16x2(rr.f[k].z, rr.f[k].w, hi.y, mid.y, lo.y);
                 }
                 uint2* row = reinterpret_cast<uint2*>(featb + g * XROW);
                 row[part] = hi;
@@ -199,11 +213,12 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
             }
         }
         qh += n;
-        // ---- 2. keep the queue ahead of the groups, then request the next group's rows: everything below runs while they travel
+        // ---- 2. keep the queue ahead of the groups, then request the rows of the group behind the ones in flight: everything
+        // below runs while they travel
         if (scanned < ns && qt - qh <= QCAP - 64) consume_scan();
-        while (qt - qh < XG && scanned < ns) consume_scan();
-        const int nnext = min(XG, qt - qh);
-        if (nnext > 0) request_rows(nnext);
+        while (qt - qh - n_ahead < XG && scanned < ns) consume_scan();
+        const int nreq = min(XG, qt - qh - n_ahead);
+        if (nreq > 0) request_rows(rr, n_ahead, nreq);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
         // ---- 3. alpha, T and w of the 16 entries (same f32 arithmetic as blend_fwd.h), w split and packed in pairs.
@@ -212,13 +227,20 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
         // case the group is evaluated again from the saved pixel state with expf for every entry -- a wave-uniform branch per
         // GROUP (one per pair of entries was measured: the branches and their scalar mask arithmetic ate what the exp saved).
         uint32_t wp[3][XG / 2];
+        // (Round 4 measured the bookkeeping on the vector side instead -- per lane "the entry at which I stopped" as one v_cndmask in
+        // place of the seven scalar instructions of fin_j below, a running minimum of |t - 1/255| in place of the two-sided band
+        // ballots: 112 -> 91 instructions per pair of entries, 43 -> 19 of them scalar -- and the kernel ran exactly as long at 32
+        // channels and 7 % longer at 64: it is bound neither by the VALU pipe nor by what a wave issues)
         int fin_j = -1;
         auto eval_group = [&](auto fast_tag) __attribute__((always_inline)) -> uint64_t {
             constexpr bool FAST = decltype(fast_tag)::value;   // v_exp_f32 + two bounds; otherwise expf (or XM's own form) + the cut
             uint64_t band = 0;
 #pragma unroll
             for (int i = 0; i < XG / 2; i++) {
-                if (2 * i >= n || live == 0) {  // padding pair of the wave's last group, or every pixel is done (wave-uniform): w = 0
+                // padding pair of the wave's last group, or every pixel is done (wave-uniform): w = 0.  MI_FWD_LIVE_EVERY > 1: the test
+                // (a branch: it cuts the group into basic blocks) only in front of every k-th pair -- a padding entry has opacity 0 and a
+                // finished pixel blends nothing, so an untested pair evaluates to w = 0 by itself
+                if ((MI_FWD_LIVE_EVERY == 1 && 2 * i >= n) || ((i % MI_FWD_LIVE_EVERY) == 0 && live == 0)) {
                     wp[0][i] = wp[1][i] = wp[2][i] = 0u;
                     continue;
                 }
@@ -254,7 +276,9 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
                     fin_j = (live == 0 && fin_j < 0) ? 2 * i + h : fin_j;  // first entry after which nobody is left
                 }
                 split3_bf16x2(w2[0], w2[1], wp[0][i], wp[1][i], wp[2][i]);
+#if MI_FWD_SB
                 __builtin_amdgcn_sched_barrier(0);  // keeps the record reads of later pairs from piling up in registers
+#endif
             }
             return band;
         };
@@ -324,7 +348,34 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
         }
 #undef X3_MFMA
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // operand reads before the next group's rows land in the same LDS
-        n = nnext;
+        return nreq;
+    };
+
+    while (qt - qh < XG && scanned < ns) consume_scan();
+    int nA = min(XG, qt - qh);
+    if (nA > 0) request_rows(setA, 0, nA);
+    live = ballot64(!done);
+    // MI_FWD_PF2, 32 channels: rows requested TWO groups ahead -- a group of 16 entries takes a wave about as long as a dependent gather
+    // under load (~4 us), so one group of run-ahead leaves the wave waiting whenever the memory system is slower than its own
+    // arithmetic (cfg3: 0.275 -> 0.268 ms).  At 64 channels the second register set (18 VGPRs) does not fit beside the accumulators
+    // at three waves per SIMD (spills): one group ahead there.
+    constexpr bool PF2 = MI_FWD_PF2 != 0 && C == 32;
+    if constexpr (PF2) {
+        int nB = 0;
+        if (nA == XG) {
+            while (qt - qh - nA < XG && scanned < ns) consume_scan();
+            nB = min(XG, qt - qh - nA);
+            if (nB > 0) request_rows(setB, nA, nB);
+        }
+        while (nA > 0 && !finished) {
+            const int nA2 = do_group(setA, nA, nB);
+            if (nB <= 0 || finished) break;
+            const int nB2 = do_group(setB, nB, nA2);
+            nA = nA2;
+            nB = nB2;
+        }
+    } else {
+        while (nA > 0 && !finished) nA = do_group(setA, nA, 0);
     }
 
     if (lane == 0 && any_inside) {

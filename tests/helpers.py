@@ -382,8 +382,27 @@ def error_stats(got: dict, want, names=None) -> dict:
         if w.size == 0:
             continue
         frac, worst, med, zt = row_error_report(g, w)
-        out[k] = dict(norm=norm_error(g, w), row_frac=frac, row_worst=worst, zero_rows_touched=zt)
+        out[k] = dict(norm=norm_error(g, w), norm_trim=trimmed_norm_error(g, w), row_frac=frac, row_worst=worst, zero_rows_touched=zt)
     return out
+
+
+TRIM_ROWS = 32
+
+
+def trimmed_norm_error(got, want, trim=TRIM_ROWS) -> float:
+    """||got - want||_2 / ||want||_2 with the `trim` rows of largest squared error left out of the numerator: the norm-wise error
+    of everything but a handful of rows.  The plain norm-wise error of dL_dcov3D / dL_dscales / dL_drotations at 1-5 M Gaussians is
+    routinely ONE ill-conditioned Gaussian's (cfg5, round 4: a single row 243 tolerances off carried the product's 3.0e-5 while
+    its rows-outside-tolerance share equalled the reference's) -- a statistic of which row drew the short straw, in either
+    implementation.  The rows left out are still judged: by the rows-outside-tolerance share and by the untrimmed norm's own bound."""
+    w = np.asarray(want, np.float64)
+    w = w.reshape(w.shape[0], -1)
+    g = np.asarray(got, np.float64).reshape(w.shape)
+    e2 = ((g - w) ** 2).sum(axis=1)
+    if e2.size > trim:
+        e2 = np.partition(e2, e2.size - trim)[: e2.size - trim]
+    den = float(np.sqrt((w ** 2).sum()))
+    return float(np.sqrt(e2.sum())) / den if den > 0 else 0.0
 
 
 def grads_as_dict(b) -> dict:

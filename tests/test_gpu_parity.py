@@ -104,7 +104,7 @@ def test_hybrid_exp_takes_the_decisions_of_expf(case):
     """Product default of the wave-per-quadrant forward (csrc/common.h "HYBRID evaluation"): v_exp_f32(x log2e) away from the
     alpha >= 1/255 cut, the device library's expf for every pair of entries in which some pixel comes within 4e-6 (relative) of
     it.  Against MI_RAST_EXACT_EXP (expf everywhere = what a build of the reference's kernels computes): the image agrees to
-    3e-6 of its scale (measured: 1.3e-6), final_T to 3e-6 relative, and n_contrib -- the last entry each pixel blended -- on all but a handful of
+    3e-6 of its scale (measured: 1.3e-6), final_T to 1.2e-5 relative (1e-6 per factor), and n_contrib -- the last entry each pixel blended -- on all but a handful of
     pixels (T < 1e-4 stop decisions that sit within an ulp or two; no tolerance for the 1/255 decisions: a flipped one moves
     n_contrib on its pixel AND the image there by ~0.4 %, which the bound on the image would catch)."""
     if case == "features32":
@@ -129,7 +129,10 @@ def test_hybrid_exp_takes_the_decisions_of_expf(case):
     assert np.abs(a - b).max() <= 1e-3 * scale    # (one entry more or less at T ~ 1e-4)
     # (a pixel whose T < 1e-4 stop fell the other way differs by one blended entry: counted with n_contrib below)
     same = ih["n_contrib"] == ie["n_contrib"]
-    np.testing.assert_allclose(ih["final_T"][same], ie["final_T"][same], rtol=3e-6, atol=0)
+    # final_T is a product of (1 - alpha) factors, each alpha within ~1e-6 (relative) of the expf form's: the relative difference of the
+    # product is bounded by 1e-6 * sum alpha / (1 - alpha) <~ 1e-6 * ln(1 / T) -- 9e-6 where T has come down to 1e-4 (measured: 3.03e-6
+    # on one pixel of 230 399, 1.3e-6 typical)
+    np.testing.assert_allclose(ih["final_T"][same], ie["final_T"][same], rtol=1.2e-5, atol=0)
     nc = float((ih["n_contrib"] != ie["n_contrib"]).mean())
     print(f"hybrid vs expf ({case}): image max diff {np.abs(a - b).max() / scale:.1e} of scale, n_contrib differs on {nc:.1e} of the pixels")
     assert nc <= 2e-5, nc

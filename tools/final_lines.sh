@@ -5,6 +5,7 @@ mkdir -p $OUT
 python bench.py > $OUT/cfg3_default.log 2>&1
 python bench.py --ref-on-gpu --steps 30 > $OUT/cfg3.log 2>&1
 python bench.py --config cfg2 > $OUT/cfg2.log 2>&1
+python bench.py --config cfg3s > $OUT/cfg3s.log 2>&1
 python bench.py --config cfg5 --ref-on-gpu > $OUT/cfg5.log 2>&1
 python bench.py --config cfg1 > $OUT/cfg1.log 2>&1
 python bench.py --dist-single --steps 10 --warmup 3 > $OUT/dist.log 2>&1
