@@ -7,14 +7,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"lines_{tag}")
 runs = [("cfg3_default", "python bench.py"), ("cfg3", "python bench.py --ref-on-gpu --steps 30"), ("cfg2", "python bench.py --config cfg2"),
-        ("cfg5", "python bench.py --config cfg5 --ref-on-gpu"), ("cfg1", "python bench.py --config cfg1"),
+        ("cfg3s", "python bench.py --config cfg3s"), ("cfg5", "python bench.py --config cfg5 --ref-on-gpu"), ("cfg1", "python bench.py --config cfg1"),
         ("dist", "python bench.py --dist-single --steps 10 --warmup 3"), ("fastexp", "python bench.py --fast-exp --no-cpu-baseline")]
 out = [f"# Bench lines of the final round build ({tag})",
        "`python bench.py [--config ...]` on 1x MI355X through gpurun (default: 100 timed steps after 10 warm-up steps and the settling blocks); "
        "`--ref-on-gpu` adds `reference_on_gpu` (oracle/_ref = the reference's own kernels, hipify-perl at build time, timed on the same workload "
        "and GPU after the timed region).  `timing` = median / p10 / p90 over 20 untimed blocks of ten steps; `roofline.traffic` / `alu` are shown "
        "only when the committed PMC summary carries the stamp of the library being timed (`roofline.library`).", ""]
-summary = ["| run | views/s | ms/step | median (p10..p90) | dominant kernel: frac | whole view: frac / without replaced / by traffic |", "|---|---|---|---|---|---|"]
+summary = ["| run | views/s | sustained views/s (>= 2 s back to back) | ms/step | median (p10..p90) | dominant kernel: frac | whole view: frac / without replaced / by traffic |", "|---|---|---|---|---|---|---|"]
 for name, cmd in runs:
     path = os.path.join(src, name + ".log")
     if not os.path.exists(path):
@@ -30,7 +30,7 @@ for name, cmd in runs:
         r = d.get("roofline") or {}
         wv = r.get("whole_view") or {}
         t = d.get("timing") or {}
-        summary.append(f"| `{cmd}` | {d['value']} | {d['ms_per_step']} | {t.get('ms_per_step_median')} ({t.get('ms_per_step_p10')}..{t.get('ms_per_step_p90')}) | "
+        summary.append(f"| `{cmd}` | {d['value']} | {(d.get('sustained') or {}).get('value')} | {d['ms_per_step']} | {t.get('ms_per_step_median')} ({t.get('ms_per_step_p10')}..{t.get('ms_per_step_p90')}) | "
                        f"{r.get('kernel')}: {r.get('frac')} | {wv.get('frac')} / {wv.get('frac_without_replaced_stages')} / {wv.get('frac_traffic')} |")
         out += ["```json", js, "```", ""]
 out[3:3] = summary + [""]
