@@ -125,11 +125,12 @@ int mi_rast_forward(
 
 /* List modes and the features-ready event (both per call).
  * flags & MI_RAST_FULL_LISTS == 0 (default): "lean" -- only the (Gaussian, tile) overlaps that pass the
- *    exact-conservative cull are listed and sorted; blend-list positions (and n_contrib, tile_consumed) count blend-list
- *    records.  Every output of the reference API (images, radii, gradients, num_rendered) is identical to the full mode's.
- * flags & MI_RAST_FULL_LISTS: "full" -- additionally materialises the reference's point_list
- *    (CF/cuda_rasterizer/rasterizer_impl.cu:300-317) and full-list positions, so that the integer path can be compared
- *    bit-exactly with the oracle / the reference.
+ *    exact-conservative cull are listed and sorted; list positions (and n_contrib, tile_consumed) count the entries of
+ *    those lists.  Every output of the reference API (images, radii, gradients, num_rendered) is identical to the full mode's.
+ * flags & MI_RAST_FULL_LISTS: "full" -- every overlap of the reference's rects is listed (the culled ones with an empty
+ *    quadrant mask, which the blend kernels skip): the lists are the reference's point_list
+ *    (CF/cuda_rasterizer/rasterizer_impl.cu:300-317) and positions its full-list positions, so that the integer path can be
+ *    compared bit-exactly with the oracle / the reference.
  * features_ready_event: training loops in which the geometry is frozen and only colors_precomp (the feature rows) is
  *    optimised -- SAGA's contrastive feature training, scene/gaussian_model_ff.py:154-162 -- may start a forward before
  *    the features are final: preprocess, depth order, binning and the per-tile sort read the geometry only.  When not NULL,
@@ -215,8 +216,11 @@ enum { MI_GEOM_DEPTHS = 0, MI_GEOM_MEANS2D, MI_GEOM_CONIC_OPACITY, MI_GEOM_COV3D
        MI_GEOM_CLAMPED, MI_GEOM_TILES_TOUCHED, MI_GEOM_DEPTH_KEY, MI_GEOM_INDEX_REC,
        MI_GEOM_SORTED_IDX, MI_GEOM_SORT_TEMP, MI_GEOM_BWD_PACK, MI_GEOM_RANK_REC, MI_GEOM_NFIELDS };
 enum { MI_IMG_FINAL_T = 0, MI_IMG_N_CONTRIB, MI_IMG_RANGES, MI_IMG_TILE_CONSUMED, MI_IMG_TILE_COUNT,
-       MI_IMG_TILE_CURSOR, MI_IMG_NUM_RENDERED, MI_IMG_BLEND_COUNT, MI_IMG_TILE_NSURV, MI_IMG_NFIELDS };
-enum { MI_BIN_ENTRIES = 0, MI_BIN_SCRATCH, MI_BIN_POINT_LIST, MI_BIN_BLEND_REC, MI_BIN_NFIELDS };
+       MI_IMG_TILE_CURSOR, MI_IMG_NUM_RENDERED, MI_IMG_TILE_NSURV, MI_IMG_NFIELDS };
+/* MI_BIN_BLEND_LIST: u32[R], per tile at ranges[tile].x in depth order: Gaussian id | quadrant mask << 28 -- all the blend kernels
+ * read of a tile's list (they gather the 32-byte record MI_GEOM_INDEX_REC[id] next to the feature row).  Full lists: every overlap
+ * of the reference's rects is an entry (culled ones with mask 0), so the low 28 bits ARE the reference's point_list. */
+enum { MI_BIN_ENTRIES = 0, MI_BIN_SCRATCH, MI_BIN_BLEND_LIST, MI_BIN_NFIELDS };
 size_t mi_rast_geometry_layout(int P, size_t* offsets /* [MI_GEOM_NFIELDS] */);
 size_t mi_rast_image_layout(int width, int height, size_t* offsets /* [MI_IMG_NFIELDS] */);
 size_t mi_rast_binning_layout(int R, size_t* offsets /* [MI_BIN_NFIELDS] */);

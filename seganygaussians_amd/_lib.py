@@ -11,8 +11,8 @@ RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 MI_GEOM_FIELDS = ["depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped", "tiles_touched",
                   "depth_key", "index_rec", "sorted_idx", "sort_temp", "bwd_pack", "rank_rec"]
-MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed", "tile_count", "tile_cursor", "num_rendered", "blend_count", "tile_nsurv"]
-MI_BIN_FIELDS = ["entries", "scratch", "point_list", "blend_rec"]
+MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed", "tile_count", "tile_cursor", "num_rendered", "tile_nsurv"]
+MI_BIN_FIELDS = ["entries", "scratch", "blend_list"]
 MI_RAST_FULL_LISTS, MI_RAST_F32_BLEND, MI_RAST_NO_CULL, MI_RAST_FAST_EXP, MI_RAST_VERIFY_LISTS, MI_RAST_TILE_FWD = 1, 2, 4, 8, 16, 32   # `flags` of mi_rast_forward (include/mi_rast.h)
 MI_RAST_PREZERO_BWD = 64   # forward + the one backward of that forward (include/mi_rast.h)
 MI_RAST_EXACT_EXP = 128    # forward blend with expf for every pair instead of the hybrid form (include/mi_rast.h)

@@ -15,8 +15,8 @@
 //   4. rank emission: each (Gaussian, tile) overlap takes its slot from an LDS cursor and stores the 4-byte RANK
 //      (arrival order inside a tile is arbitrary within a slice);
 //   5. per-tile LDS radix sort of the ranks (<= 24 significant bits, 8-bit digits, stable wave-match
-//      ranking), then point_list[slot] = sorted_idx[rank].
-// HBM traffic per overlap drops from ~172 B to ~16 B (4 B emit write, 4 B sort read, 4 B point_list
+//      ranking), then blend_list[slot] = sorted_idx[rank] | quadrant mask << 28 (full lists: the low 28 bits are point_list).
+// HBM traffic per overlap drops from ~172 B to ~16 B (4 B emit write, 4 B sort read, 4 B list
 // write, 4 B L2-resident gather); the 64-bit keys are never materialised.
 #pragma once
 
@@ -183,9 +183,9 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
     }
 }
 
-// A survivor of the exact-conservative cull (cull.h), as the blend kernels consume it: everything needed to
-// evaluate the Gaussian at a pixel in ONE coalesced 32-byte record (the reference gathers id -> xy -> conic
-// per batch with dependent loads, forward.cu:318-326).
+// Everything needed to evaluate a Gaussian at a pixel in ONE 32-byte record (the reference gathers id -> xy -> conic per batch
+// with dependent loads, forward.cu:318-326): written per Gaussian by the preprocess pass (index_rec, `pm` = radius), permuted into
+// depth-rank order for the binning passes (rank_rec), and what the blend kernels stage per list entry.
 struct __attribute__((aligned(16))) BlendRec {
     float2 xy;       // pixel-space mean
     uint32_t id;     // Gaussian index (feature row)
@@ -193,6 +193,17 @@ struct __attribute__((aligned(16))) BlendRec {
     float4 co;       // conic A,B,C + opacity
 };
 static_assert(sizeof(BlendRec) == 32, "BlendRec must be 32 bytes");
+
+// Entry i of a tile's blend list (4 bytes: Gaussian id | quadrant mask << 28, see emit_blend_list below) as a full record: the
+// geometry record of that Gaussian (index_rec, written by the preprocess pass) with `pm` = position << 4 | quadrant mask.  For the
+// kernels that walk a list in whole batches (blend_fwd.h, blend_bwd.h); the wave kernels gather per quadrant.
+__device__ __forceinline__ BlendRec list_record(const uint32_t* __restrict__ lst, const BlendRec* __restrict__ index_rec, int i)
+{
+    const uint32_t e = lst[i];
+    BlendRec r = index_rec[e & RANK_MASK];
+    r.pm = ((uint32_t)i << 4) | (e >> RANK_BITS);
+    return r;
+}
 
 // ---- per-rank geometry records ------------------------------------------------------------------------
 // After the depth sort, the per-Gaussian data the binning stages need (pixel mean, conic, opacity, radius, id)
@@ -242,8 +253,8 @@ inline int bin_workgroups(int P)
 
 // Emit pass of the FULL lists (the reference's `debug` flag, MI_RAST_FULL_LISTS: parity tests): every overlap of the
 // reference's rects is stored, with the quadrant mask the lean lists would give it (cull.h: span_tile_mask; 0 = culled) in
-// the top 4 bits -- the per-tile sort then reproduces the reference's point_list and gathers a blend record only for entries
-// that blend.  NOCULL (testing aid, MI_RAST_NO_CULL): every overlap is kept with all four quadrant bits.
+// the top 4 bits -- the per-tile sort then reproduces the reference's point_list (the low 28 bits of the blend list), and the blend
+// kernels skip the entries without a mask bit.  NOCULL (testing aid, MI_RAST_NO_CULL): every overlap is kept with all four quadrant bits.
 // The product default does not come here: bin_spans_kernel below.
 template <bool NOCULL = false>
 __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
@@ -438,11 +449,16 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
     __syncthreads();
     const int nwg = (int)gridDim.x;
     const int rounds = ((P + 63) / 64 + 16 * nwg - 1) / (16 * nwg);
+    // The record of the NEXT round is requested before this round's items are walked (a round is a chain of workgroup barriers
+    // and LDS searches with one workgroup per CU: nothing else would hide the load).  Unconditional, index clamped: a
+    // conditionally assigned load result is waited for on the spot.
+    BlendRec nxt = rank_rec[min((wave * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
     for (int it = 0; it < rounds; it++) {
         const int r = ((it * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
+        const BlendRec rec = nxt;
+        nxt = rank_rec[min((((it + 1) * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
         uint32_t h = 0;
         if (r < P) {
-            const BlendRec rec = rank_rec[r];
             const int rad = (int)rec.pm;
             if (rad > 0) {
                 uint2 rmin, rmax;
@@ -691,82 +707,23 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
     __syncthreads();
 }
 
-// Emits point_list (the reference-exact sorted id list) and the compacted blend list of the tile: entries whose
-// quadrant mask is non-zero, in list order, at blend_rec[range.x ...], count in blend_count.
-// Latency is what this phase is made of (two dependent gathers per entry), so no workgroup barrier sits between
-// consecutive loads: every wave owns a contiguous share of the sorted list; pass 1 writes point_list and counts the
-// wave's survivors, one barrier exchanges the counts, pass 2 lists the survivors' positions in `spare` (order
-// preserved: shares are contiguous), and pass 3 gathers the 32-byte records of the survivors on dense lanes.
-template <int NW, typename SrcPtr, typename SparePtr>
-__device__ __forceinline__ void emit_tile_lists(SrcPtr sorted_entries, SparePtr spare, int n, uint2 range, int tid,
-                                                const uint32_t* __restrict__ sorted_idx,
-                                                const BlendRec* __restrict__ rank_rec,
-                                                uint32_t* __restrict__ point_list, BlendRec* __restrict__ blend_rec,
-                                                uint32_t* __restrict__ blend_count, uint32_t tile, uint32_t* s_wcount)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    uint32_t* out = point_list + range.x;
-    BlendRec* rec = blend_rec + range.x;
-    const int chunks = (n + 63) >> 6;
-    const int cpw = (chunks + NW - 1) / NW;
-    const int begin = min(n, wave * cpw * 64), end = min(n, (wave + 1) * cpw * 64);
-    // pass 1: point_list; survivors of this wave's share
-    uint32_t mine = 0;
-    for (int i0 = begin; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        uint32_t keep = 0;
-        if (i < end) {
-            const uint32_t e = sorted_entries[i];
-            out[i] = sorted_idx[e & RANK_MASK];
-            keep = (e >> RANK_BITS) != 0u;
-        }
-        mine += (uint32_t)__builtin_popcountll(ballot64(keep != 0u));
-    }
-    if (lane == 0) s_wcount[wave] = mine;
-    __syncthreads();
-    uint32_t base = 0, ns = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        const uint32_t c = s_wcount[w];
-        base += w < wave ? c : 0u;
-        ns += c;
-    }
-    // pass 2: positions of the survivors, in list order
-    for (int i0 = begin; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const bool keep = i < end && ((uint32_t)sorted_entries[i] >> RANK_BITS) != 0u;
-        const uint64_t bal = ballot64(keep);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (keep) spare[base + below] = (uint32_t)i;
-        base += (uint32_t)__builtin_popcountll(bal);
-    }
-    __syncthreads();
-    // pass 3: records of the survivors (dense, no barriers: the gathers of successive iterations overlap)
-    for (int j = tid; j < (int)ns; j += NW * 64) {
-        const uint32_t i = spare[j];
-        const uint32_t e = sorted_entries[i];
-        BlendRec r = rank_rec[e & RANK_MASK];
-        r.pm = (i << 4) | (e >> RANK_BITS);
-        rec[j] = r;
-    }
-    if (tid == 0) blend_count[tile] = ns;
-}
-
-// Lean lists: every sorted entry is a survivor; its position in the blend list stands in for the position in the
-// reference's full list (the blend kernels only compare positions of one list with each other).
+// The tile's BLEND LIST: the sorted entries with the depth rank replaced by the Gaussian id, id | quadrant mask << 28, four bytes
+// per overlap at blend_list[range.x ...].  This is all the blend kernels get of a tile: they scan the entries 64 at a time (256
+// contiguous bytes), queue the ones whose bit for their quadrant is set and gather the 32-byte geometry record index_rec[id] next to
+// the feature row of the same id -- two independent gathers behind one scan.  (Rounds 1-4 materialised a 32-byte blend record per
+// entry here: a 94-MB gather and a 94-MB store per cfg3 view for lists of which the blends walk a third.)  The position of an entry
+// in its list is its index -- n_contrib's unit.  Full lists (bin_ranks_kernel): every overlap of the reference's rects is an entry,
+// culled ones with mask 0, so blend_list & RANK_MASK IS the reference's point_list and the index its position there; lean lists
+// (bin_spans_kernel): the entries that can blend only.
 template <int NW, typename SrcPtr>
-__device__ __forceinline__ void emit_blend_list(SrcPtr sorted_entries, int m, uint2 range, int tid,
-                                                const BlendRec* __restrict__ rank_rec, BlendRec* __restrict__ blend_rec,
-                                                uint32_t* __restrict__ blend_count, uint32_t tile)
+__device__ __forceinline__ void emit_blend_list(SrcPtr sorted_entries, int n, uint2 range, int tid,
+                                                const uint32_t* __restrict__ sorted_idx, uint32_t* __restrict__ blend_list)
 {
-    BlendRec* rec = blend_rec + range.x;
-    for (int j = tid; j < m; j += NW * 64) {
-        const uint32_t e = sorted_entries[j];
-        BlendRec r = rank_rec[e & RANK_MASK];
-        r.pm = ((uint32_t)j << 4) | (e >> RANK_BITS);
-        rec[j] = r;
+    uint32_t* out = blend_list + range.x;
+    for (int i = tid; i < n; i += NW * 64) {
+        const uint32_t e = sorted_entries[i];
+        out[i] = sorted_idx[e & RANK_MASK] | (e & ~RANK_MASK);
     }
-    if (tid == 0) blend_count[tile] = (uint32_t)m;
 }
 
 // MI_RAST_VERIFY_LISTS (include/mi_rast.h): the lean lists rest on the count pass and the emit pass taking bit-identical float
@@ -784,21 +741,17 @@ __global__ void __launch_bounds__(256) verify_entries_kernel(uint32_t ntiles, co
     if (n) atomicAdd(unwritten, n);
 }
 
-template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT, bool FULL = true>
+template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT>
 __global__ void __launch_bounds__(NT) tile_sort_kernel(uint32_t ntiles, const uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ entries,
                                                         uint32_t* __restrict__ scratch,
-                                                        const uint32_t* __restrict__ sorted_idx,
-                                                        const BlendRec* __restrict__ rank_rec,
-                                                        uint32_t* __restrict__ point_list, int passes,
-                                                        BlendRec* __restrict__ blend_rec,
-                                                        uint32_t* __restrict__ blend_count)
+                                                        const uint32_t* __restrict__ sorted_idx, int passes,
+                                                        uint32_t* __restrict__ blend_list)
 {
     __shared__ uint32_t s_a[CAP];
     __shared__ uint32_t s_b[CAP];
     constexpr int NW = NT / 64;
     __shared__ uint32_t s_hist[NW][256];
-    __shared__ uint32_t s_wcount[NW];
     const int tid = threadIdx.x;
     // (tile = workgroup id: neighbouring tiles on different XCDs.  Contiguous runs per XCD -- common.h -- save 3 % here through
     // the rank records neighbouring tiles share, but the cost of a tile is its list length, and a static split would let a
@@ -807,36 +760,32 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(uint32_t ntiles, const ui
     if (tile >= ntiles) return;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (LO == 0 && n == 0 && tid == 0) blend_count[tile] = 0u;
     if (n <= LO) return;
     if (n > CAP && !GLOBAL_FALLBACK) return;
     uint32_t* seg = entries + range.x;
     if (n <= CAP) {
-        const int m = n;  // lean lists too: their counts are exact (bin_spans_kernel), every slot of the segment holds an entry
+        // (lean lists too: their counts are exact -- bin_spans_kernel --, every slot of the segment holds an entry)
         for (int i = tid; i < n; i += NT) s_a[i] = seg[i];
         __syncthreads();
         uint32_t* a = s_a;
         uint32_t* b = s_b;
         for (int p = 0; p < passes; p++) {
-            radix_pass<NW, (CAP + NW * 64 - 1) / (NW * 64)>(a, b, m, 8 * p, s_hist, tid);
+            radix_pass<NW, (CAP + NW * 64 - 1) / (NW * 64)>(a, b, n, 8 * p, s_hist, tid);
             uint32_t* t = a;
             a = b;
             b = t;
         }
-        if (FULL) emit_tile_lists<NW>(a, b, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, tile, s_wcount);
-        else emit_blend_list<NW>(a, m, range, tid, rank_rec, blend_rec, blend_count, tile);
+        emit_blend_list<NW>(a, n, range, tid, sorted_idx, blend_list);
     } else {
         uint32_t* a = seg;
         uint32_t* b = scratch + range.x;
-        const int m = n;
         for (int p = 0; p < passes; p++) {
-            radix_pass<NW, 0>(a, b, m, 8 * p, s_hist, tid);
+            radix_pass<NW, 0>(a, b, n, 8 * p, s_hist, tid);
             uint32_t* t = a;
             a = b;
             b = t;
         }
-        if (FULL) emit_tile_lists<NW>(a, b, n, range, tid, sorted_idx, rank_rec, point_list, blend_rec, blend_count, tile, s_wcount);
-        else emit_blend_list<NW>(a, m, range, tid, rank_rec, blend_rec, blend_count, tile);
+        emit_blend_list<NW>(a, n, range, tid, sorted_idx, blend_list);
     }
 }
 

@@ -41,7 +41,8 @@ constexpr int ROWS = 128;    // survivor rows (features + gradient accumulators)
 
 template <int C, bool MASKGRAD, bool XEXP = false>
 __global__ void __launch_bounds__(256) blend_bwd_kernel(
-    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
+    const uint32_t* __restrict__ tile_nsurv,
     int W, int H, const float* __restrict__ bg_color, const float* __restrict__ colors,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dout_mask, float* __restrict__ gpack /*[P,8] packed field gradients*/,
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     if (Lt == 0) return;
     // blend-list records the forward walked for this tile: a superset of every contributing entry
     const int NS = (int)tile_nsurv[tile];
-    const BlendRec* rec = blend_rec + range.x;
+    const uint32_t* lst = blend_list + range.x;   // four-byte entries; list_record (binning.h) gathers the geometry record of one
 
     const float T_final = inside ? final_Ts[pix_id] : 0;
     float T = T_final;
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     };
 
     BlendRec cur;
-    if (tid < ROWS && tid < NS) cur = rec[NS - 1 - tid];
+    if (tid < ROWS && tid < NS) cur = list_record(lst, index_rec, NS - 1 - tid);
 
     for (int b0 = 0; b0 < NS; b0 += ROWS) {
         const int nr = min(ROWS, NS - b0);  // records in this batch, walked back to front
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 for (int ch = 0; ch < C; ch++) s_feat[tid * ROW + ch] = colors[(size_t)cur.id * C + ch];
             }
         }
-        if (tid < ROWS && b0 + ROWS + tid < NS) cur = rec[NS - 1 - (b0 + ROWS + tid)];
+        if (tid < ROWS && b0 + ROWS + tid < NS) cur = list_record(lst, index_rec, NS - 1 - (b0 + ROWS + tid));
         // ---- B: features of this batch; clear the tile accumulators
         if constexpr (WIDE) {
             constexpr int F4 = C / 4;
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 const int q = tid + BATCH * k;
                 const int g = q / F4, part = q % F4;
                 if (g < nr)
-                    s_feat4[g * F4 + part] = reinterpret_cast<const float4*>(colors + (size_t)rec[NS - 1 - (b0 + g)].id * C)[part];
+                    s_feat4[g * F4 + part] = reinterpret_cast<const float4*>(colors + (size_t)(lst[NS - 1 - (b0 + g)] & RANK_MASK) * C)[part];
             }
         }
         if constexpr (C > 0 && !WIDE)

@@ -8,11 +8,11 @@
 // quadrant's records out of the batch and pads them to a multiple of 16 rows PER BATCH: on cfg3 18 % of all chunk rows
 // are padding, the waves of a tile meet at two barriers per batch (14 % of wave time), and a wave with few rows idles
 // while the tile's busiest quadrant works.  Here a workgroup IS one wave:
-//   * the wave scans the tile's records itself, 64 at a time (one 8-byte {id, position|quadrant mask} quarter per lane,
-//     prefetched one block ahead), and appends the records of its quadrant to a ring in LDS (128 entries = 8 chunks of
-//     run-ahead), so chunks are always full -- only the wave's very last chunk is padded;
-//   * the 16 rows of the NEXT chunk (one 8-byte record quarter per lane + two float4 feature parts per lane) are
-//     requested before the current chunk is processed and wait in registers;
+//   * the wave scans the tile's blend list itself, 64 entries at a time (four bytes each: Gaussian id | quadrant mask << 28,
+//     binning.h; prefetched one block ahead), and appends the entries of its quadrant to a ring in LDS (128 entries = 8 chunks
+//     of run-ahead), so chunks are always full -- only the wave's very last chunk is padded;
+//   * the 16 rows of the NEXT chunk (one 8-byte quarter of the geometry record index_rec[id] per lane + two float4 feature
+//     parts per lane, both gathered by the id) are requested before the current chunk is processed and wait in registers;
 //   * every chunk issues the SAME number of memory instructions (the gradient atomics are unconditional: rows without
 //     a contributing pixel add exact zeros), so the in-order vmcnt wait for the staged rows never has to cover the
 //     atomics issued after them;
@@ -81,8 +81,8 @@ struct BwvCfg {
 // STRIDED: rows of `colors` / `dL_dcolors` are `cstride_arg` floats apart (one channel block of a wider feature); otherwise CR.
 template <int C, int CR = C, bool MASKGRAD = false, int WPB = 1, bool XEXP = false, bool STRIDED = false>
 __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
-    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ tile_nsurv,
-    int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ bg_color,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
+    const uint32_t* __restrict__ tile_nsurv, int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ bg_color,
     const float* __restrict__ colors, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dout_mask,
     float* __restrict__ gpack /*[P,8] packed field gradients*/, float* __restrict__ dL_dcolors,
@@ -159,15 +159,15 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wave_Lt = max(wave_Lt, __shfl_xor(wave_Lt, o, 64));
     wave_Lt = __builtin_amdgcn_readfirstlane(wave_Lt);
-    // List positions (n_contrib's unit) are indices into the blend list (lean lists) or into the full tile list (full
-    // lists, position >= index): either way no record at index >= wave_Lt can reach this quadrant.
+    // List positions (n_contrib's unit) are indices into the tile's blend list: no entry at index >= wave_Lt can reach this quadrant.
     const int NS = min(NS_tile, wave_Lt);   // 0: nothing blended into this quadrant -- the wave leaves after the staging
     // below (not here: with an exit in between, hipcc sinks the gradient-image loads behind it, i.e. behind this wait)
-    const BlendRec* rec = NS > 0 ? blend_rec + range.x : blend_rec;  // record j of the walk (back to front) is rec[NS - 1 - j]
+    // entry = Gaussian id | quadrant mask << 28 (binning.h); entry j of the walk (back to front) is lst[NS - 1 - j]
+    const uint32_t* lst = NS > 0 ? blend_list + range.x : blend_list;
 
     // first scan block.  Scan loads are unconditional (clamped index): a conditional assignment makes hipcc copy the
     // register right behind the load, i.e. wait for it on the spot.
-    uint2 scan_reg = reinterpret_cast<const uint2*>(rec + max(0, NS - 1 - min(lane, NS - 1)))[1];
+    uint32_t scan_reg = lst[max(0, NS - 1 - min(lane, NS - 1))];
     __builtin_amdgcn_sched_barrier(0);  // ... and the scan load behind the gradient-image staging
     float T = T_final;
     TK(0);
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
     if (NS == 0) return;
     const float nTb = -T_final * bg_dot_dpixel;  // the background term of dL/dalpha is nTb / (1 - alpha)
     const bool has_bg = ballot64(nTb != 0.f) != 0;   // wave-uniform
-    const int last4 = last_contributor << 4, wave_Lt4 = wave_Lt << 4;  // compared with (position << 4 | mask)
+    const int last4 = last_contributor << 4;  // compared with (position << 4 | mask)
 
     // MI_BWD_SEPMOM (default): the six moments are separable, x^a y^b.  Stage 1 contracts over x on the matrix pipe with
     // v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks, K = 1, 8 cycles): block (row group rg = (lane >> 2) & 3, pixel row
@@ -258,19 +258,18 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
 
     // ---- the queue of this quadrant's records
     int scanned = 0, qh = 0, qt = 0;
-    // Consumes the prefetched scan block [scanned, scanned + 64): candidates = records whose quadrant bit is set and whose
-    // list position is below the quadrant's largest n_contrib; requests the next block.
+    // Consumes the prefetched scan block [scanned, scanned + 64): candidates = entries whose quadrant bit is set (every position
+    // walked is below the quadrant's largest n_contrib: NS <= wave_Lt); requests the next block.
     auto consume_scan = [&]() {
         const int j = scanned + lane;
-        const int pmv = (int)scan_reg.y;
-        const bool cand = j < NS && ((pmv >> quad) & 1) != 0 && pmv < wave_Lt4;
+        const bool cand = j < NS && ((scan_reg >> (RANK_BITS + quad)) & 1u) != 0;
         const uint64_t bal = ballot64(cand);
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg.x);
+        if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg);
         qt += __builtin_popcountll(bal);
         scanned += 64;
         if (prof) n_scans++;
-        scan_reg = reinterpret_cast<const uint2*>(rec + (NS - 1 - min(scanned + lane, NS - 1)))[1];
+        scan_reg = lst[NS - 1 - min(scanned + lane, NS - 1)];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
     // Requests the rows queue[qh .. qh + n), n >= 1, of the next chunk: record quarter (lane & 3) of row (lane >> 2) and the
@@ -285,14 +284,14 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
         asm volatile("" : "+v"(l));
         {
             const int rq = min(l >> 2, n - 1), qq = l & 3;
-            const uint32_t j = s_queue[(qh + rq) & (QCAP - 1)].x;
-            curq = reinterpret_cast<const uint2*>(rec + (NS - 1 - (int)j))[qq];
+            const uint32_t gq = s_queue[(qh + rq) & (QCAP - 1)].y & RANK_MASK;
+            curq = reinterpret_cast<const uint2*>(index_rec + gq)[qq];
         }
 #pragma unroll
         for (int k = 0; k < NK; k++) {
             const int e = l + 64 * k;
             const int g = min(e / F4, n - 1), part = e % F4;
-            const size_t gid = (size_t)s_queue[(qh + g) & (QCAP - 1)].y;
+            const size_t gid = (size_t)(s_queue[(qh + g) & (QCAP - 1)].y & RANK_MASK);
             if constexpr (CR == C) {
                 featpf[k] = reinterpret_cast<const float4*>(colors + gid * (size_t)cstride)[part];
             } else if constexpr (CR == 0) {  // partial block: channel by channel, zeros behind cr (never reads past the row)
@@ -351,9 +350,11 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
         // exact zeros to some real row instead costs dearly: same-address atomics serialise at ~22 ns each).
         {
             const int rq = lane >> 2, qq = lane & 3;
-            // quarter 0 = {x, y} -> bytes 0..7; 1 = {id, pm} -> {pm, id} at 24; 2 = {a, b} -> {-a/2, -b} at 8; 3 = {c, opacity} -> {-c/2, opacity} at 16
+            // quarter 0 = {x, y} -> bytes 0..7; 1 = {id, radius} -> {position << 4 | mask, id} at 24 (from the queue); 2 = {a, b} ->
+            // {-a/2, -b} at 8; 3 = {c, opacity} -> {-c/2, opacity} at 16
             float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
-            if (qq == 1) v = make_float2(__uint_as_float(curq.y), __uint_as_float(curq.x));
+            const uint2 qe = s_queue[(qh + (FULL ? rq : min(rq, nrows - 1))) & (QCAP - 1)];   // {walk index j, id | mask << 28}
+            if (qq == 1) v = make_float2(__uint_as_float(((uint32_t)(NS - 1 - (int)qe.x) << 4) | (qe.y >> RANK_BITS)), __uint_as_float(qe.y & RANK_MASK));
             if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
             if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
             if (!FULL) {

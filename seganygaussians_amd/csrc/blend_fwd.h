@@ -7,8 +7,8 @@
 // gfx950 mapping: one 256-thread workgroup per 16x16 tile (the tile size is part of the integer
 // contract), four wave64s each owning an 8x8 pixel quadrant.  The kernel does not walk the raw tile list:
 // it streams the tile's BLEND LIST (binning.h), i.e. only the entries that can reach alpha >= 1/255
-// somewhere in the tile (about one third of the list on the benchmark scene), as coalesced 32-byte records
-// that already hold xy / conic / opacity / id / list position / quadrant mask -- no dependent gathers.
+// somewhere in the tile (about one third of the list on the benchmark scene): four-byte entries id | quadrant mask,
+// each completed by ONE gather of the Gaussian's 32-byte geometry record (xy / conic / opacity; binning.h: list_record).
 // Per batch of FB records:
 //   A. record -> LDS; the NEXT batch's record is already in flight in registers while this one is blended;
 //   B. the C feature floats of every record are staged into LDS with coalesced 16-B loads (8 lanes cover one
@@ -43,7 +43,7 @@ struct FeatStage {
 // planes are written.
 template <int C, int EXTRA, bool XEXP = false, bool PARTIAL = false>
 __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fwd_kernel(
-    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
     int W, int H, const float* __restrict__ features, const float* __restrict__ mask, const float* __restrict__ depths,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed,
     uint32_t* __restrict__ tile_nsurv, const float* __restrict__ bg_color, float* __restrict__ out_color,
@@ -91,8 +91,8 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fw
 
     const uint2 range = ranges[tile];
     const int list_len = (int)(range.y - range.x);
-    const int ns_total = (int)blend_count[tile];
-    const BlendRec* rec = blend_rec + range.x;
+    const int ns_total = list_len;
+    const uint32_t* lst = blend_list + range.x;   // four-byte entries; list_record (binning.h) gathers the geometry record of one
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fw
     }
 
     BlendRec cur;
-    if (tid < FB && tid < ns_total) cur = rec[tid];
+    if (tid < FB && tid < ns_total) cur = list_record(lst, index_rec, tid);
 
     for (int b0 = 0; b0 < ns_total; b0 += FB) {
         // whole workgroup finished? (also the barrier that protects LDS reuse)
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256, (C == 32 && EXTRA == 0) ? 4 : 1) blend_fw
                 if (lane == 0) s_bits[q][wave] = b;
             }
         }
-        if (tid < FB && b0 + FB + tid < ns_total) cur = rec[b0 + FB + tid];
+        if (tid < FB && b0 + FB + tid < ns_total) cur = list_record(lst, index_rec, b0 + FB + tid);
         if constexpr (VEC_STAGE) {
             // ---- B: features, gathered by the ids just staged in LDS (a second trip to the records in memory
             // would put one more ~4 us dependent access in front of every batch)

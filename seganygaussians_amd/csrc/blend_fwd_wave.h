@@ -8,8 +8,9 @@
 //     four quadrant waves of a tile in lockstep (a batch lasts as long as its busiest quadrant), every quadrant's list padded
 //     to a multiple of 16 entries PER BATCH.  The kernel is VALU-bound (alpha evaluation: ~37 VALU per (wave, entry)) at four
 //     waves per SIMD, so every cycle a wave waits at a barrier is a cycle the SIMD has three waves to issue from;
-//   * here a workgroup IS one wave: it scans the tile's records itself (64 {id, position|mask} quarters per block, one block
-//     prefetched), queues the records of its quadrant in an LDS ring, and works through them in FULL groups of 16 entries
+//   * here a workgroup IS one wave: it scans the tile's blend list itself (64 four-byte entries id | quadrant mask << 28 per
+//     block, one block prefetched), queues the entries of its quadrant in an LDS ring, and works through them in FULL groups of 16
+//     (the 32-byte geometry record index_rec[id] and the feature row of an entry are gathered side by side)
 //     -- only a wave's last group is padded.  The 16 records and feature rows of the NEXT group are requested before the
 //     current group is evaluated and wait in registers (2 + 2 C / 32 ... VGPRs); a wave leaves as soon as its 64 pixels are
 //     done.  The four quadrants of a tile are four workgroups on the same XCD (blockIdx -> (tile, quadrant) as in the backward).
@@ -82,7 +83,7 @@ __device__ __forceinline__ void fwd_zero_fill(const FwdZeroFill& z, uint32_t wg,
 // XM: how opacity * exp(power) is evaluated (common.h: ExpMode) -- EXP_HYBRID is the product default.
 template <int C, int XM = EXP_HYBRID, bool STRIDED = false>
 __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64) blend_fwd_wave_kernel(
-    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed /* zeroed: receives atomicMax */,
     uint32_t* __restrict__ tile_nsurv /* zeroed: receives atomicMax */, const float* __restrict__ bg_color,
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
     const int cstride = STRIDED ? cstride_arg : C;
     __shared__ XRec s_rec[XG];
     __shared__ uint4 s_feat4[XG * XROW / 16];
-    __shared__ uint2 s_queue[QCAP];     // {record index in the blend list, Gaussian id}
+    __shared__ uint2 s_queue[QCAP];     // {position in the blend list, entry = Gaussian id | quadrant mask << 28}
     __shared__ uint32_t s_j[XG];        // blend-list index of the group's entries
     static_assert(XG * XROW >= 8 * 65 * 4, "feature buffer too small for the epilogue transpose");
     char* const featb = reinterpret_cast<char*>(s_feat4);
@@ -116,8 +117,8 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
     const uint2 range = ranges[tile];
     const int list_len = (int)(range.y - range.x);
     const bool any_inside = ballot64(inside) != 0;
-    const int ns = any_inside ? (int)blend_count[tile] : 0;
-    const BlendRec* rec = blend_rec + range.x;
+    const int ns = any_inside ? list_len : 0;
+    const uint32_t* lst = blend_list + range.x;   // entry = Gaussian id | quadrant mask << 28 (binning.h); its position is its index
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
@@ -136,17 +137,17 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
 
     // ---- the queue of this quadrant's records
     int scanned = 0, qh = 0, qt = 0;
-    uint2 scan_reg = make_uint2(0u, 0u);
-    if (ns > 0) scan_reg = reinterpret_cast<const uint2*>(rec + min(lane, ns - 1))[1];
+    uint32_t scan_reg = 0u;
+    if (ns > 0) scan_reg = lst[min(lane, ns - 1)];
     auto consume_scan = [&]() {
         const int j = scanned + lane;
-        const bool cand = j < ns && ((scan_reg.y >> quad) & 1u) != 0;
+        const bool cand = j < ns && ((scan_reg >> (RANK_BITS + quad)) & 1u) != 0;
         const uint64_t bal = ballot64(cand);
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg.x);
+        if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg);
         qt += __builtin_popcountll(bal);
         scanned += 64;
-        scan_reg = reinterpret_cast<const uint2*>(rec + min(scanned + lane, ns - 1))[1];
+        scan_reg = lst[min(scanned + lane, ns - 1)];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
     // Requests the rows queue[qh + ahead .. qh + ahead + n), n >= 1, of a coming group into one of the two register sets: record
@@ -161,14 +162,14 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
             const int rq = min(lane >> 2, n - 1), qq = lane & 3;
-            const uint32_t j = s_queue[(qh + ahead + rq) & (QCAP - 1)].x;
-            rr.q = reinterpret_cast<const uint2*>(rec + j)[qq];
+            const uint32_t gq = s_queue[(qh + ahead + rq) & (QCAP - 1)].y & RANK_MASK;
+            rr.q = reinterpret_cast<const uint2*>(index_rec + gq)[qq];
         }
 #pragma unroll
         for (int k = 0; k < NK; k++) {
             const int e = lane + 64 * k;
             const int g = min(e / F4, n - 1), part = e % F4;
-            const size_t gid = (size_t)s_queue[(qh + ahead + g) & (QCAP - 1)].y;
+            const size_t gid = (size_t)(s_queue[(qh + ahead + g) & (QCAP - 1)].y & RANK_MASK);
             rr.f[k] = reinterpret_cast<const float4*>(features + gid * (size_t)cstride)[part];
         }
     };
@@ -184,9 +185,11 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
         {
             const uint2 curq = rr.q;
             const int rq = lane >> 2, qq = lane & 3;
-            // quarter 0 = {x, y}; 1 = {id, pm} -> {position + 1, pm}; 2 = {a, b} -> {-a/2, -b}; 3 = {c, opacity} -> {-c/2, opacity}
+            // quarter 0 = {x, y}; 1 = {id, radius} -> {position + 1, position << 4 | mask} (from the queue); 2 = {a, b} -> {-a/2, -b};
+            // 3 = {c, opacity} -> {-c/2, opacity}
             float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
-            if (qq == 1) v = make_float2(__uint_as_float((curq.y >> 4) + 1u), __uint_as_float(curq.y));
+            const uint2 qe = s_queue[(qh + min(rq, n - 1)) & (QCAP - 1)];   // {position, id | mask << 28}
+            if (qq == 1) v = make_float2(__uint_as_float(qe.x + 1u), __uint_as_float((qe.x << 4) | (qe.y >> RANK_BITS)));
             if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
             if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
             if (rq >= n) {
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
             }
             const int dst = qq == 0 ? 0 : (qq == 1 ? 24 : (qq == 2 ? 8 : 16));
             *reinterpret_cast<float2*>(reinterpret_cast<char*>(&s_rec[rq]) + dst) = v;
-            if (qq == 1) s_j[rq] = s_queue[(qh + min(rq, n - 1)) & (QCAP - 1)].x;
+            if (qq == 1) s_j[rq] = qe.x;
 #pragma unroll
             for (int k = 0; k < NK; k++) {
                 const int e = lane + 64 * k;
@@ -426,7 +429,7 @@ namespace mirast {
 // the arithmetic of blend_fwd.h, bit for bit), the 16 rows of a group staged as {r, g, b, mask, depth} floats.
 template <int EXTRA, int XM = EXP_HYBRID>
 __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
-    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features /* [P,3] */,
     const float* __restrict__ mask, const float* __restrict__ depths, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed, uint32_t* __restrict__ tile_nsurv,
@@ -455,8 +458,8 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     const uint2 range = ranges[tile];
     const int list_len = (int)(range.y - range.x);
     const bool any_inside = ballot64(inside) != 0;
-    const int ns = any_inside ? (int)blend_count[tile] : 0;
-    const BlendRec* rec = blend_rec + range.x;
+    const int ns = any_inside ? list_len : 0;
+    const uint32_t* lst = blend_list + range.x;   // entry = Gaussian id | quadrant mask << 28 (binning.h); its position is its index
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
@@ -467,17 +470,17 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     for (int ch = 0; ch < CE; ch++) acc[ch] = 0.f;
 
     int scanned = 0, qh = 0, qt = 0;
-    uint2 scan_reg = make_uint2(0u, 0u);
-    if (ns > 0) scan_reg = reinterpret_cast<const uint2*>(rec + min(lane, ns - 1))[1];
+    uint32_t scan_reg = 0u;
+    if (ns > 0) scan_reg = lst[min(lane, ns - 1)];
     auto consume_scan = [&]() {
         const int j = scanned + lane;
-        const bool cand = j < ns && ((scan_reg.y >> quad) & 1u) != 0;
+        const bool cand = j < ns && ((scan_reg >> (RANK_BITS + quad)) & 1u) != 0;
         const uint64_t bal = ballot64(cand);
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg.x);
+        if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg);
         qt += __builtin_popcountll(bal);
         scanned += 64;
-        scan_reg = reinterpret_cast<const uint2*>(rec + min(scanned + lane, ns - 1))[1];
+        scan_reg = lst[min(scanned + lane, ns - 1)];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
     // next group's rows: record quarter (lane & 3) of row (lane >> 2); lane l feeds value (l & 7) of row (l >> 3) and (l >> 3) + 8
@@ -487,13 +490,13 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
             const int rq = min(lane >> 2, n - 1), qq = lane & 3;
-            const uint32_t j = s_queue[(qh + rq) & (QCAP - 1)].x;
-            curq = reinterpret_cast<const uint2*>(rec + j)[qq];
+            const uint32_t gq = s_queue[(qh + rq) & (QCAP - 1)].y & RANK_MASK;
+            curq = reinterpret_cast<const uint2*>(index_rec + gq)[qq];
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int g = min((lane >> 3) + 8 * k, n - 1), c = lane & 7;
-            const size_t gid = (size_t)s_queue[(qh + g) & (QCAP - 1)].y;
+            const size_t gid = (size_t)(s_queue[(qh + g) & (QCAP - 1)].y & RANK_MASK);
             float v = 0.f;
             if (c < C) v = features[gid * 3 + c];
             else if (EXTRA >= 1 && c == C) v = mask[gid];
@@ -512,7 +515,8 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
         {
             const int rq = lane >> 2, qq = lane & 3;
             float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
-            if (qq == 1) v = make_float2(__uint_as_float((curq.y >> 4) + 1u), __uint_as_float(curq.y));
+            const uint2 qe = s_queue[(qh + min(rq, n - 1)) & (QCAP - 1)];   // {position, id | mask << 28}
+            if (qq == 1) v = make_float2(__uint_as_float(qe.x + 1u), __uint_as_float((qe.x << 4) | (qe.y >> RANK_BITS)));
             if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
             if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
             if (rq >= n) {
@@ -522,7 +526,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
             }
             const int dst = qq == 0 ? 0 : (qq == 1 ? 24 : (qq == 2 ? 8 : 16));
             *reinterpret_cast<float2*>(reinterpret_cast<char*>(&s_rec[rq]) + dst) = v;
-            if (qq == 1) s_j[rq] = s_queue[(qh + min(rq, n - 1)) & (QCAP - 1)].x;
+            if (qq == 1) s_j[rq] = qe.x;
 #pragma unroll
             for (int k = 0; k < 2; k++) s_f[((lane >> 3) + 8 * k) * FROW + (lane & 7)] = fpf[k];
         }

@@ -31,7 +31,7 @@ constexpr int XB = 128;    // blend-list records per batch
 // C = 64: two 32-channel accumulator pairs (64 VGPRs), 24 MFMA per group, rows of 384 bytes: 2 workgroups per CU.
 template <int C, bool XEXP = false, bool STRIDED = false>
 __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
-    const uint2* __restrict__ ranges, const BlendRec* __restrict__ blend_rec, const uint32_t* __restrict__ blend_count,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
     int W, int H, const float* __restrict__ features, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_consumed, uint32_t* __restrict__ tile_nsurv, const float* __restrict__ bg_color,
     float* __restrict__ out_color, int cstride_arg /* STRIDED: floats between feature rows (blend_fwd.h) */)
@@ -68,8 +68,8 @@ __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
 
     const uint2 range = ranges[tile];
     const int list_len = (int)(range.y - range.x);
-    const int ns_total = (int)blend_count[tile];
-    const BlendRec* rec = blend_rec + range.x;
+    const int ns_total = (int)(range.y - range.x);
+    const uint32_t* lst = blend_list + range.x;
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
     const int chan2 = 2 * (lane & 31);  // byte offset of this lane's channel inside a bf16 plane
 
     BlendRec cur;
-    if (tid < XB && tid < ns_total) cur = rec[tid];
+    if (tid < XB && tid < ns_total) cur = list_record(lst, index_rec, tid);
 
     for (int b0 = 0; b0 < ns_total; b0 += XB) {
         if (__syncthreads_and(done)) break;  // whole workgroup finished? (also the barrier that protects LDS reuse)
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256, C == 32 ? 4 : 2) blend_fwd_x3_kernel(
             // pins every loaded value in registers here: hipcc otherwise sinks each load into the guarded store below
 #pragma unroll
             for (int k = 0; k < NK; k++) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
-            if (tid < XB && b0 + XB + tid < ns_total) cur = rec[b0 + XB + tid];  // after the gather: vmcnt retires in order
+            if (tid < XB && b0 + XB + tid < ns_total) cur = list_record(lst, index_rec, b0 + XB + tid);  // after the gather: vmcnt retires in order
 #pragma unroll
             for (int k = 0; k < NK; k++) {
                 const int q = tid + BATCH * k;

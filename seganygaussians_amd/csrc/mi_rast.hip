@@ -21,9 +21,6 @@
 #include "knn_smooth.h"
 #include "knn.h"
 #include "blend_bwd.h"
-#ifdef MI_RAST_PROFILING
-#include "blend_bwd_mfma.h"  // round 1's tile-batched kernel: A/B comparisons only (MI_RAST_ABLATE=2048)
-#endif
 #include "blend_bwd_wave.h"
 #include "blend_fwd.h"
 #include "blend_fwd_wave.h"
@@ -249,14 +246,13 @@ struct ImgPtrs {
     uint32_t* tile_count;
     uint32_t* tile_cursor;
     int* num_rendered;
-    uint32_t* blend_count;  // per tile: records in its blend list
-    uint32_t* tile_nsurv;   // per tile: blend-list records the forward walked
+    uint32_t* tile_nsurv;   // per tile: blend-list entries the forward walked
 };
 struct BinPtrs {
     uint32_t* entries;   // per overlap: depth rank of the Gaussian, bucketed by tile (unsorted inside a tile)
     uint32_t* scratch;   // ping-pong buffer for tiles too long for the LDS sort
-    uint32_t* point_list;
-    BlendRec* blend_rec;  // per tile at range.x: compacted survivor records (binning.h)
+    uint32_t* blend_list;  // per tile at range.x, in depth order: Gaussian id | quadrant mask << 28 (binning.h: emit_blend_list); full
+                           // lists: the low 28 bits are the reference's point_list
 };
 
 GeomPtrs geom_from(char* base, int P)
@@ -291,7 +287,6 @@ ImgPtrs img_from(char* base, int W, int H)
     m.tile_count = (uint32_t*)(base + off[MI_IMG_TILE_COUNT]);
     m.tile_cursor = (uint32_t*)(base + off[MI_IMG_TILE_CURSOR]);
     m.num_rendered = (int*)(base + off[MI_IMG_NUM_RENDERED]);
-    m.blend_count = (uint32_t*)(base + off[MI_IMG_BLEND_COUNT]);
     m.tile_nsurv = (uint32_t*)(base + off[MI_IMG_TILE_NSURV]);
     return m;
 }
@@ -302,8 +297,7 @@ BinPtrs bin_from(char* base, int R)
     BinPtrs b;
     b.entries = (uint32_t*)(base + off[MI_BIN_ENTRIES]);
     b.scratch = (uint32_t*)(base + off[MI_BIN_SCRATCH]);
-    b.point_list = (uint32_t*)(base + off[MI_BIN_POINT_LIST]);
-    b.blend_rec = (BlendRec*)(base + off[MI_BIN_BLEND_REC]);
+    b.blend_list = (uint32_t*)(base + off[MI_BIN_BLEND_LIST]);
     return b;
 }
 
@@ -538,16 +532,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             // some tile needs it.  The longest list was copied to the host right after the range scan, which
             // finished before the emit pass above even started: this wait does not stall the queue.
 #define LAUNCH_TILE_SORT(LO, CAP, FB, NT)                                                                                 \
-    do {                                                                                                                  \
-        if (full)                                                                                                         \
-            hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT, true>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges,  \
-                               bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,          \
-                               bin.blend_rec, img.blend_count);                                                           \
-        else                                                                                                              \
-            hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT, false>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges, \
-                               bin.entries, bin.scratch, geom.sorted_idx, geom.rank_rec, bin.point_list, passes,          \
-                               bin.blend_rec, img.blend_count);                                                           \
-    } while (0)
+    hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges,  \
+                       bin.entries, bin.scratch, geom.sorted_idx, passes, bin.blend_list)
             LAUNCH_TILE_SORT(0, 2048, false, 256);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
             // lean lists: the counts are the lists' exact lengths (bin_spans_kernel), their sum a lower bound of R
@@ -560,9 +546,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         }
         STAGE_CHECK("tile sort");
     } else {
-        // no overlap at all: the per-tile sort, which writes every tile's blend_count otherwise, does not run
-        HIP_TRY(hipMemsetAsync(img.blend_count, 0, (size_t)ntiles * sizeof(uint32_t), stream));
-        // the range scan stores {total, longest list} into this thread's pinned words: never return while that store can still
+        // no overlap at all (every tile's range is {0, 0}: the blend kernels read no list).  The range scan stores {total, longest list} into this thread's pinned words: never return while that store can still
         // land (the next forward of this thread, on another stream, would read them)
         HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
     }
@@ -578,7 +562,7 @@ void launch_blend_fwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& i
     const int g_ablate_fwd = ablate_env("MI_RAST_ABLATE_FWD");
 #define TILE_FWD_LAUNCH(XE, PART)                                                                                                     \
     hipLaunchKernelGGL((blend_fwd_kernel<C, EXTRA, XE, PART>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,              \
-                       bin.blend_rec, img.blend_count, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,              \
+                       bin.blend_list, geom.index_rec, vp.W, vp.H, features, mask, geom.depths, img.final_T, img.n_contrib,              \
                        img.tile_consumed, img.tile_nsurv, bg, out_color, out_mask, out_depth, cstride, cr, g_ablate_fwd)
     if constexpr (C == 16 && EXTRA == 0) {   // the remainder block of a feature: `cr` < 16 of its channels may exist (blend_fwd.h PARTIAL)
         if (cr < C) {
@@ -594,12 +578,12 @@ void launch_blend_fwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& i
 
 #ifdef MI_RAST_PROFILING
 template <int C>
-void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const float* features,
-                         const float* bg, float* out_color, bool xexp, int cstride)
+void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const GeomPtrs& geom,
+                         const float* features, const float* bg, float* out_color, bool xexp, int cstride)
 {
 #define X3_LAUNCH(XE, ST)                                                                                                           \
-    hipLaunchKernelGGL((blend_fwd_x3_kernel<C, XE, ST>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_rec,  \
-                       img.blend_count, vp.W, vp.H, features, img.final_T, img.n_contrib, img.tile_consumed, img.tile_nsurv, bg,        \
+    hipLaunchKernelGGL((blend_fwd_x3_kernel<C, XE, ST>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges, bin.blend_list, \
+                       geom.index_rec, vp.W, vp.H, features, img.final_T, img.n_contrib, img.tile_consumed, img.tile_nsurv, bg,         \
                        out_color, cstride)
     if (cstride == C) {
         if (xexp) X3_LAUNCH(true, false);
@@ -615,16 +599,16 @@ void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs
 // One wave per (tile, quadrant): 32 x the longest XCD run of tiles workgroups (blend_fwd_wave.h).
 // xm: common.h ExpMode -- EXP_HYBRID unless the caller's flags say otherwise (exp_mode_of)
 template <int C>
-void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const float* features,
-                           const float* bg, float* out_color, int xm, int cstride, FwdZeroFill& zfill)
+void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const GeomPtrs& geom,
+                           const float* features, const float* bg, float* out_color, int xm, int cstride, FwdZeroFill& zfill)
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
     const uint32_t grid = 32u * ((nt + 7u) >> 3);
     const FwdZeroFill zf = zfill;
     zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};   // taken: the launches of further channel blocks fill nothing
 #define FW_LAUNCH(XM, ST)                                                                                                     \
-    hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XM, ST>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec,            \
-                       img.blend_count, vp.W, vp.H, vp.grid_x, nt, features, img.final_T, img.n_contrib, img.tile_consumed,       \
+    hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XM, ST>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_list,           \
+                       geom.index_rec, vp.W, vp.H, vp.grid_x, nt, features, img.final_T, img.n_contrib, img.tile_consumed,        \
                        img.tile_nsurv, bg, out_color, cstride, zf)
 #define FW_LAUNCH_ST(ST)                                  \
     do {                                                  \
@@ -648,7 +632,7 @@ void launch_blend_fwd_wave_rgb(const ViewParams& vp, hipStream_t stream, const I
     const FwdZeroFill zf = zfill;
     zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};
 #define RGB_LAUNCH(XM)                                                                                                                       \
-    hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, XM>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_rec, img.blend_count,    \
+    hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, XM>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_list, geom.index_rec,   \
                        vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,                 \
                        img.tile_nsurv, bg, out_color, out_mask, out_depth, zf)
     if (xm == EXP_HYBRID) RGB_LAUNCH(EXP_HYBRID);
@@ -665,11 +649,11 @@ void launch_blend_bwd(const ViewParams& vp, hipStream_t stream, const ImgPtrs& i
     const int g_ablate = ablate_env("MI_RAST_ABLATE");
     if (xexp)
         hipLaunchKernelGGL((blend_bwd_kernel<C, MASKGRAD, true>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                           bin.blend_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
+                           bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
                            dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate);
     else
         hipLaunchKernelGGL((blend_bwd_kernel<C, MASKGRAD, false>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,
-                           bin.blend_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
+                           bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, bg, colors, img.final_T, img.n_contrib, dL_dpix,
                            dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate);
 }
 
@@ -943,7 +927,6 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     off[MI_IMG_TILE_COUNT] = c.take((size_t)BIN_MAX_WG * (tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_NUM_RENDERED] = c.take((R_SLOTS * R_SLOT_STRIDE + 4) * sizeof(int));  // R partial sums, then {R, longest list}
-    off[MI_IMG_BLEND_COUNT] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_NSURV] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     return c.off;
 }
@@ -953,8 +936,7 @@ size_t mi_rast_binning_layout(int R, size_t* off)
     Carver c;
     off[MI_BIN_ENTRIES] = c.take(r * sizeof(uint32_t));
     off[MI_BIN_SCRATCH] = c.take(r * sizeof(uint32_t));
-    off[MI_BIN_POINT_LIST] = c.take(r * sizeof(uint32_t));
-    off[MI_BIN_BLEND_REC] = c.take(r * sizeof(BlendRec));
+    off[MI_BIN_BLEND_LIST] = c.take(r * sizeof(uint32_t));
     return c.off;
 }
 
@@ -1079,17 +1061,17 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
                 if (cb == 64) {
 #ifdef MI_RAST_PROFILING
                     if (f32_blend) launch_blend_fwd<64, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
-                    else if (tile_fwd) launch_blend_fwd_x3<64>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                    else if (tile_fwd) launch_blend_fwd_x3<64>(vp, stream, img, bin, geom, f, bgp, out, xexp, channels);
                     else
 #endif
-                    launch_blend_fwd_wave<64>(vp, stream, img, bin, f, bgp, out, xm, channels, zfill);
+                    launch_blend_fwd_wave<64>(vp, stream, img, bin, geom, f, bgp, out, xm, channels, zfill);
                 } else if (cb == 32) {
 #ifdef MI_RAST_PROFILING
                     if (f32_blend) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
-                    else if (tile_fwd) launch_blend_fwd_x3<32>(vp, stream, img, bin, f, bgp, out, xexp, channels);
+                    else if (tile_fwd) launch_blend_fwd_x3<32>(vp, stream, img, bin, geom, f, bgp, out, xexp, channels);
                     else
 #endif
-                    launch_blend_fwd_wave<32>(vp, stream, img, bin, f, bgp, out, xm, channels, zfill);
+                    launch_blend_fwd_wave<32>(vp, stream, img, bin, geom, f, bgp, out, xm, channels, zfill);
                 } else {
                     launch_blend_fwd<16, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels,
                                             std::min(16, channels - c0));
@@ -1142,14 +1124,10 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         float* dcolor_blk = dL_dcolor;
         int cstride = channels;
         int cr_blk = 0;   // channels of a partial block that exist (blend_bwd_wave.h: CR == 0)
-#define LAUNCH_BWD_MFMA(...)                                                                                              \
-    hipLaunchKernelGGL((blend_bwd_mfma_kernel<__VA_ARGS__>), dim3(vp.grid_x, vp.grid_y), dim3(256), 0, stream, img.ranges,    \
-                       bin.blend_rec, img.tile_nsurv, vp.W, vp.H, background, color_ptr, img.final_T, img.n_contrib, dL_dpix, \
-                       dL_dout_mask, geom.bwd_pack, dL_dcolor, g_ablate)
         const uint32_t nt_ = vp.grid_x * vp.grid_y;
 #define LAUNCH_BWD_WAVE_(WPB, XE, ST, ...)                                                                                    \
     hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE, ST>), dim3(WPB == 1 ? 32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_) : nt_), dim3(64 * WPB), 0,    \
-                       stream, img.ranges, bin.blend_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
+                       stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
                        img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk, g_ablate)
 #ifdef MI_RAST_PROFILING
 #define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
@@ -1172,12 +1150,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         else LAUNCH_BWD_WAVE_ST(true, C_, CR_, MG_);                                \
     } while (0)
 #ifdef MI_RAST_PROFILING
-        if (g_ablate & 2048) {  // the tile-batched MFMA kernel (blend_bwd_mfma.h), for comparisons
-            if (maskgrad) LAUNCH_BWD_MFMA(16, 3, true);
-            else if (channels == 3) LAUNCH_BWD_MFMA(16, 3, false);
-            else if (channels == 32) LAUNCH_BWD_MFMA(32);
-            else LAUNCH_BWD_MFMA(64);
-        } else if (g_ablate & 1024) {  // the VALU kernels (timing comparisons)
+        if (g_ablate & 1024) {  // the VALU kernels (timing comparisons)
             if (maskgrad) launch_blend_bwd<3, true>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, dL_dout_mask, dL_dcolor, xexp);
             else if (channels == 3) launch_blend_bwd<3, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor, xexp);
             else if (channels == 32) launch_blend_bwd<32, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor, xexp);
@@ -1208,10 +1181,9 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
 #undef LAUNCH_BWD_WAVE
 #undef LAUNCH_BWD_WAVE_ST
 #undef LAUNCH_BWD_WAVE_
-#undef LAUNCH_BWD_MFMA
     }
 #ifdef MI_RAST_PROFILING
-    if ((g_ablate & 32) && !(g_ablate & 2048)) {
+    if ((g_ablate & 32) && !(g_ablate & 1024)) {
         float dbg[8 * 13];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);

@@ -178,28 +178,29 @@ class GpuRun:
                     sorted_idx=self._view(self.geom, off["sorted_idx"], P, np.uint32))
 
     def bin_fields(self):
+        """point_list: the low 28 bits of the blend list -- with full lists the reference's sorted id list, bit for bit."""
         from seganygaussians_amd import _lib
         R = self.num_rendered
         _, off = _lib.binning_layout(R)
-        return dict(point_list=self._view(self.binning, off["point_list"], R, np.uint32))
+        bl = self._view(self.binning, off["blend_list"], R, np.uint32)
+        return dict(point_list=bl & np.uint32(0x0FFFFFFF), blend_list=bl)
 
     def blend_lists(self):
-        """The per-tile blend lists (what the blend kernels walk): concatenated Gaussian ids and quadrant masks in list
-        order, plus the per-tile counts.  Positions (pm >> 4) depend on the list mode and are not returned."""
-        from seganygaussians_amd import _lib
+        """The per-tile blend lists as the blend kernels walk them: concatenated Gaussian ids and quadrant masks in list order
+        (entries without a quadrant bit -- the culled overlaps a full list carries -- left out: no kernel stops at them), plus the
+        per-tile counts of what is left.  Positions depend on the list mode and are not returned."""
         R = self.num_rendered
-        i = self.inp
-        W, H = i.image_width, i.image_height
-        tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        _, ioff = _lib.image_layout(W, H)
-        counts = self._view(self.img, ioff["blend_count"], tiles, np.uint32).astype(np.int64)
-        if R == 0:
-            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), counts
-        _, off = _lib.binning_layout(R)
-        rec = self._view(self.binning, off["blend_rec"], 8 * R, np.uint32).reshape(R, 8)
         ranges = self.img_fields()["ranges"].reshape(-1, 2).astype(np.int64)
-        sel = np.concatenate([np.arange(a, a + c) for (a, _), c in zip(ranges, counts) if c]) if counts.sum() else np.zeros(0, np.int64)
-        return rec[sel, 2].copy(), (rec[sel, 3] & 15).copy(), counts
+        if R == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(len(ranges), np.int64)
+        bl = self.bin_fields()["blend_list"]
+        lens = ranges[:, 1] - ranges[:, 0]
+        sel = np.concatenate([np.arange(a, b) for a, b in ranges if b > a]) if lens.sum() else np.zeros(0, np.int64)
+        tiles = np.repeat(np.arange(len(ranges)), lens)
+        e = bl[sel]
+        keep = (e >> np.uint32(28)) != 0
+        counts = np.bincount(tiles[keep], minlength=len(ranges)).astype(np.int64)
+        return (e[keep] & np.uint32(0x0FFFFFFF)).copy(), (e[keep] >> np.uint32(28)).copy(), counts
 
     def sorted_keys(self):
         """The reference's sorted 64-bit key list (tile << 32 | depth bits), which our pipeline never

@@ -11,9 +11,14 @@ tx, ty = (W + 15) // 16, (H + 15) // 16
 R = g.num_rendered
 _, off = _lib.binning_layout(R)
 _, ioff = _lib.image_layout(W, H)
-rec = g._view(g.binning, off["blend_rec"], 8 * R, np.uint32).reshape(R, 8)
 im = g.img_fields()
 ranges = im["ranges"].reshape(-1, 2).astype(np.int64)
+# the records the blend kernels stage: index_rec[id] of every blend-list entry (id | quadrant mask << 28), pm = position << 4 | mask
+_, goff = _lib.geometry_layout(g.P)
+bl = g._view(g.binning, off["blend_list"], R, np.uint32)
+rec = g._view(g.geom, goff["index_rec"], 8 * g.P, np.uint32).reshape(g.P, 8)[bl & np.uint32(0x0FFFFFFF)]
+pos_in_tile = np.arange(R, dtype=np.int64) - np.repeat(ranges[:, 0], ranges[:, 1] - ranges[:, 0]) if R else np.zeros(0, np.int64)
+rec[:, 3] = (pos_in_tile.astype(np.uint32) << np.uint32(4)) | (bl >> np.uint32(28))
 nsurv = g._view(g.img, ioff["tile_nsurv"], tx * ty, np.uint32).astype(np.int64)
 nc = im["n_contrib"].reshape(H, W).astype(np.int64)
 pad = np.zeros((ty * 16, tx * 16), np.int64); pad[:H, :W] = nc
