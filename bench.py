@@ -22,8 +22,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
                average duration measured live with HIP events on the launch stream; peak 8000 GB/s.
                `stages` lists EVERY stage the same way; a stage whose frac exceeds 1 is flagged
                "algorithm replaced" (the reference's byte count for a pass this pipeline does not perform:
-               never read it as bandwidth).  `whole_view.frac` uses the SURVEY byte count, `whole_view.frac_traffic`
-               the HBM bytes the counters saw, `whole_view.frac_without_replaced_stages` leaves the replaced stages' bytes out.
+               never read it as bandwidth).  `whole_view.frac` leaves the replaced stages' bytes out (the number to read),
+               `whole_view.frac_survey_bytes` is SURVEY.md 8(d)'s literal byte table, `whole_view.frac_traffic` the HBM bytes the
+               counters saw.
                `traffic` / `alu` (matrix / vector pipe busy fractions of the dominant kernel) come from the committed PMC passes
                (profiles/traffic_<cfg>.json, alu_<cfg>.json) and are null unless those were taken with the library being timed
                (stamp = mi_rast_version(): a hash of sources, headers and flags).
@@ -114,6 +115,9 @@ def main():
     ap.add_argument("--cameras", default=None, help="a COLMAP scene directory (sparse/0/{cameras,images}.bin|txt): rank r renders its "
                                                     "camera --camera-index + r (sorted by image name like the reference's training list)")
     ap.add_argument("--camera-index", type=int, default=0)
+    ap.add_argument("--images", default=None, help="with --cameras: the image folder the reference run was trained on (its -i option, e.g. "
+                                                   "<scene>/images_4): the render takes the size of the camera's image FILE like the reference's "
+                                                   "loadCam; default: the COLMAP camera model's size (= the full-resolution `images` folder)")
     ap.add_argument("--resolution", type=float, default=-1, help="with --cameras: the reference's --resolution (utils/camera_utils.py:20-40): "
                                                                  "-1 = camera size, width capped at 1600; 1/2/4/8 = divisor; else target width")
     ap.add_argument("--feature-ply", default=None, help="with --ply: feature rows from a FeatureGaussianModel.save_ply file instead of seeded noise")
@@ -141,7 +145,9 @@ def main():
                     help="forward blend with the device library's expf for every pair (MI_RAST_EXACT_EXP) instead of the product "
                          "default, the hybrid form (expf only where a pixel comes within 4e-6 of the alpha >= 1/255 cut): A/B aid")
     ap.add_argument("--tile-fwd", action="store_true",
-                    help="A/B aid: 32/64-channel forward on the tile-batched kernel (MI_RAST_TILE_FWD) instead of the wave-per-quadrant one")
+                    help="A/B aid: 32/64-channel forward on the tile-batched kernel (MI_RAST_TILE_FWD) instead of the wave-per-quadrant one; "
+                         "a comparison kernel of the PROFILING build: run with MI_RAST_LIB=seganygaussians_amd/libmi_rast_prof.so "
+                         "(python -m seganygaussians_amd.build --profiling)")
     ap.add_argument("--ref-on-gpu", action="store_true",
                     help="reporting only, after the timed region: also time oracle/_ref (the reference's own kernels, translated "
                          "test-only by oracle/build_ref.py) on the same workload and GPU")
@@ -174,6 +180,11 @@ def main():
             dist.init_process_group(backend)
 
     from seganygaussians_amd import _lib, install_dropin, scenes
+    if args.tile_fwd:
+        from seganygaussians_amd import build as _build
+        if os.path.realpath(os.environ.get("MI_RAST_LIB", "")) != os.path.realpath(_build.PROF_LIB_PATH):
+            sys.exit("--tile-fwd selects a comparison kernel that only the profiling build holds: "
+                     f"MI_RAST_LIB={_build.PROF_LIB_PATH} python bench.py --tile-fwd ...  (python -m seganygaussians_amd.build --profiling builds it)")
     install_dropin()
     from seganygaussians_amd import rasterizer as R
     from seganygaussians_amd.dist import allreduce_grads_async
@@ -192,7 +203,12 @@ def main():
         P = scene.means3D.shape[0]
         cams = colmap_io.read_colmap_cameras(args.cameras)
         cc = cams[(args.camera_index + rank) % len(cams)]
-        cam = colmap_io.to_camera(cc, args.resolution)
+        # the reference sizes the render from the image FILE (utils/camera_utils.py:21): --images <dir> (e.g. the scene's images_4)
+        # reads the size of this camera's file there; without it the COLMAP camera model's size stands in (= the `images` folder)
+        img_size = None
+        if args.images:
+            img_size = colmap_io.image_size_of(os.path.join(args.images, cc.name))
+        cam = colmap_io.to_camera(cc, args.resolution, image_size=img_size)
         W, H = cam.image_width, cam.image_height
         data = f"file: {os.path.basename(os.path.dirname(os.path.abspath(args.ply))) or args.ply} ({P} Gaussians), camera {cc.name}"
     else:
@@ -483,17 +499,22 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": tr(dom),
                     "algorithmic_bytes": ab[dom], "kernel_ms": round(stages_ms[dom], 4),
                     "alu": alu, "pmc": pmc_note, "library": lib_version, "stages": stage_rows,
-                    "whole_view": {"algorithmic_bytes": ab["total"], "achieved": round(wv_ach, 1),
-                                   "frac": round(wv_ach / HBM_PEAK_GBPS, 4),
-                                   "frac_without_replaced_stages": round(wv_kept / HBM_PEAK_GBPS, 4),
+                    # whole_view.frac: the bytes of the stages this pipeline really performs (the reference's 45-bit global sort,
+                    # which it replaces, left out) / the step time -- the number to read.  frac_survey_bytes: SURVEY.md 8(d)'s
+                    # literal byte table, replaced sort included: a byte count, not bandwidth.
+                    "whole_view": {"algorithmic_bytes": kept, "achieved": round(wv_kept, 1),
+                                   "frac": round(wv_kept / HBM_PEAK_GBPS, 4),
+                                   "frac_survey_bytes": round(wv_ach / HBM_PEAK_GBPS, 4),
+                                   "survey_bytes": ab["total"],
                                    # also against what a float4 copy reaches on this part (6.3 TB/s)
-                                   "frac_of_copy_rate": round(wv_ach / 6300.0, 4),
+                                   "frac_of_copy_rate": round(wv_kept / 6300.0, 4),
                                    "traffic": total_traffic,
                                    "frac_traffic": round(total_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
                                    if total_traffic else None,
-                                   "note": "frac counts the reference algorithm's bytes (incl. its 45-bit global sort, which "
-                                           "this pipeline replaces); frac_without_replaced_stages leaves the replaced stages' bytes "
-                                           "out (same time); frac_traffic counts the HBM bytes the PMC counters saw"}}
+                                   "note": "frac leaves out the bytes of the stages whose algorithm this pipeline replaces (the "
+                                           "reference's 45-bit global sort: rows flagged 'algorithm replaced' in stages); "
+                                           "frac_survey_bytes counts SURVEY.md 8(d)'s whole table (same time): a byte count, not "
+                                           "bandwidth; frac_traffic counts the HBM bytes the PMC counters saw"}}
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N == 1 only) + parity of the benchmarked run ------
     cpu_baseline = None
@@ -518,11 +539,13 @@ def main():
             bo = None if fwd_only else so.backward(inp, fo, dLn)
             view_s.append(time.perf_counter() - c0)
         cpu_s = sum(view_s) / nviews
+        # cores = the OpenMP threads that ran (omp_get_max_threads() of the oracle library); the affinity mask and the host's CPU
+        # count are reported beside it, not mixed into it
         cpu_baseline = {"value": round(1.0 / cpu_s, 4), "unit": "views/s", "cores": so.num_threads(), "kind": "port",
+                        "affinity_cpus": len(os.sched_getaffinity(0)), "host_cpus": os.cpu_count(),
                         "sample": f"{nviews} full views {'fwd' if fwd_only else 'fwd+bwd'} of {args.config} (P={P}, {W}x{H}, C={C}), "
-                                  f"{', '.join(f'{v:.2f}' for v in view_s)} s each, OpenMP over Gaussians/tiles, "
-                                  f"gcc -O3 {'-march=native' if native else '(portable build)'}; OpenMP runs one thread on each of the "
-                                  f"{len(os.sched_getaffinity(0))} logical CPUs this process may use (affinity mask) of the host's {os.cpu_count()}"}
+                                  f"{', '.join(f'{v:.2f}' for v in view_s)} s each, OpenMP over Gaussians/tiles with "
+                                  f"{so.num_threads()} threads (omp_get_max_threads), gcc -O3 {'-march=native' if native else '(portable build)'}"}
         # parity of what was just benchmarked (product default lists) against that oracle run
         step()
         torch.cuda.synchronize(dev)

@@ -62,11 +62,14 @@ extern "C" {
                                   reference's own; still inside the 1e-4 contract).  The backward MUST be given the flags of its
                                   forward: it re-takes the same decisions */
 #define MI_RAST_EXACT_EXP 128  /* forward blend: the device library's expf for EVERY pair.  Product default (flag clear): the hybrid form of
-                                  csrc/common.h -- v_exp_f32(x * log2e) away from the alpha >= 1/255 cut, expf for every pair of list entries
-                                  in which some pixel comes within 4e-6 (relative) of it: the decisions are expf's always (the backward,
-                                  which uses expf, re-takes exactly them), alpha itself differs by <= 1e-6 relative, the image by ~1e-7
-                                  of its scale; cfg3 forward blend 0.283 -> see DESIGN.md section 11.  With the flag, alpha / T / n_contrib /
-                                  final_T are bit-identical to a build of the reference's kernels (tests) */
+                                  csrc/common.h -- v_exp_f32(x * log2e) away from the alpha >= 1/255 cut, and the whole 16-entry GROUP
+                                  re-evaluated with expf when some pixel of it comes within 4e-6 (relative) of the cut (per entry in the
+                                  RGB kernel).  What that protects is the alpha >= 1/255 decision only: those are expf's always (the
+                                  backward, which uses expf, re-takes exactly them).  The T < 1e-4 STOP test runs on the v_exp_f32 alphas
+                                  (<= 1e-6 relative off), so n_contrib / final_T can differ from a build of the reference's kernels on
+                                  about 1e-6 of the pixels (tests allow 5e-6): the default is NOT bit-identical on the image-state fields,
+                                  the image differs by ~1e-7 of its scale.  With the flag, alpha / T / n_contrib / final_T are
+                                  bit-identical to a build of the reference's kernels (tests) */
 #define MI_RAST_VERIFY_LISTS 16 /* debugging aid (lean lists only; synchronous): zero-fills the list entries before the emit pass and
                                 * fails with MI_RAST_ERR_HIP if a slot the count pass reserved was not written by the emit pass */
 #define MI_RAST_TILE_FWD 32    /* 32/64-channel forward on the tile-batched bf16x3 kernel (four lockstep waves per tile, blend_fwd_x3.h)

@@ -151,8 +151,42 @@ def render_size(width: int, height: int, resolution: float = -1) -> tuple:
     return int(width / float(down)), int(height / float(down))
 
 
-def to_camera(c: ColmapCamera, resolution: float = -1) -> scenes.Camera:
-    w, h = render_size(c.width, c.height, resolution)
+def image_size_of(path: str) -> tuple:
+    """(width, height) of a PNG or JPEG file from its header (no image library needed) -- what PIL's Image.size gives the reference's
+    loadCam (utils/camera_utils.py:21: `orig_w, orig_h = cam_info.image.size`)."""
+    import struct
+    with open(path, "rb") as f:
+        head = f.read(26)
+        if head[:8] == b"\x89PNG\r\n\x1a\n":
+            return struct.unpack(">II", head[16:24])
+        if head[:2] != b"\xff\xd8":
+            raise ValueError(f"{path}: neither PNG nor JPEG")
+        f.seek(2)
+        while True:
+            b = f.read(1)
+            while b and b != b"\xff":
+                b = f.read(1)
+            while b == b"\xff":
+                b = f.read(1)
+            if not b:
+                raise ValueError(f"{path}: no JPEG frame header")
+            m = b[0]
+            if 0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):   # SOFn
+                f.read(3)
+                h, w = struct.unpack(">HH", f.read(4))
+                return w, h
+            if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7:
+                continue
+            f.seek(struct.unpack(">H", f.read(2))[0] - 2, 1)
+
+
+def to_camera(c: ColmapCamera, resolution: float = -1, image_size: Optional[tuple] = None) -> scenes.Camera:
+    """`image_size`: (width, height) of the image FILE the reference would load for this camera.  Its loadCam sizes the render from
+    the loaded image (utils/camera_utils.py:21), not from the COLMAP camera model: a 360_v2 run with `-i images_4` renders a quarter
+    of the model's size (before --resolution applies).  Without it the camera model's size is used, which is the reference's size
+    only for the full-resolution `images` folder."""
+    w0, h0 = image_size if image_size is not None else (c.width, c.height)
+    w, h = render_size(w0, h0, resolution)
     return scenes.camera_from_fov(w, h, c.fovx, c.fovy, c.R, c.T)
 
 

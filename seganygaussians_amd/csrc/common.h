@@ -154,10 +154,13 @@ __device__ __forceinline__ float gauss_power(float ha, float nb, float hc, float
 // opacity * exp(power) only has to be the device expf's value BIT FOR BIT where it decides something -- at the alpha >= 1/255
 // cut, which the backward re-takes with expf.  Away from the cut a few ulp are float-path noise (alpha to ~6e-7 relative).  So:
 // G = v_exp_f32(power * log2e) (2 VALU; relative error <= 8 * 2^-24 * ln 2 + 1 ulp < 1e-6 wherever opacity * G can reach 1/255,
-// i.e. power >= -5.55), two compares against the cut widened by +-4e-6 relative, and a pair of entries in which ANY lane falls
-// between the two bounds is re-evaluated with the exact form (a wave-uniform branch, taken for ~1e-4 of the pairs).  A value
-// outside the band lies on the same side of the cut in both forms, so every decision is the one expf takes: the forward and the
-// backward agree on who blends, always.
+// i.e. power >= -5.55), two compares against the cut widened by +-4e-6 relative, and a GROUP of 16 entries (32/64-channel kernel;
+// one entry in the RGB kernel) in which ANY lane falls between the two bounds is re-evaluated with the exact form (a wave-uniform
+// branch, taken for ~1e-3 of the groups).  A value outside the band lies on the same side of the cut in both forms, so every
+// alpha >= 1/255 decision is the one expf takes: the forward and the backward agree on who blends, always.  ONLY that decision is
+// protected: the T < 1e-4 stop test runs on the v_exp_f32 alphas, so where a pixel stops (n_contrib, final_T) can differ from an
+// all-expf run on ~1e-6 of the pixels -- the default mode is not bit-identical to the reference on the image-state fields
+// (MI_RAST_EXACT_EXP is).
 constexpr float ALPHA_CUT = 1.0f / 255.0f;
 constexpr float ALPHA_CUT_LO = (float)((1.0 / 255.0) * (1.0 - 4e-6));
 constexpr float ALPHA_CUT_HI = (float)((1.0 / 255.0) * (1.0 + 4e-6));

@@ -21,7 +21,11 @@
 #include "knn_smooth.h"
 #include "knn.h"
 #include "blend_bwd.h"
+#ifdef MI_RAST_PROFILING
+#include "../../tools/experiments/blend_bwd_wave_lab.h"   // the same kernel with ablation masks, phase timers and rejected variants
+#else
 #include "blend_bwd_wave.h"
+#endif
 #include "blend_fwd.h"
 #include "blend_fwd_wave.h"
 #ifdef MI_RAST_PROFILING
@@ -1125,11 +1129,11 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         int cstride = channels;
         int cr_blk = 0;   // channels of a partial block that exist (blend_bwd_wave.h: CR == 0)
         const uint32_t nt_ = vp.grid_x * vp.grid_y;
+#ifdef MI_RAST_PROFILING
 #define LAUNCH_BWD_WAVE_(WPB, XE, ST, ...)                                                                                    \
     hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE, ST>), dim3(WPB == 1 ? 32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_) : nt_), dim3(64 * WPB), 0,    \
                        stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
                        img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk, g_ablate)
-#ifdef MI_RAST_PROFILING
 #define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
     do {                                                                            \
         if (xexp) LAUNCH_BWD_WAVE_(1, true, ST, __VA_ARGS__);                       \
@@ -1137,10 +1141,14 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         else LAUNCH_BWD_WAVE_(1, false, ST, __VA_ARGS__);                           \
     } while (0)
 #else
+#define LAUNCH_BWD_WAVE_(XE, ST, ...)                                                                                         \
+    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, XE, ST>), dim3(32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_)), dim3(64), 0,    \
+                       stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
+                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk)
 #define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
     do {                                                                            \
-        if (xexp) LAUNCH_BWD_WAVE_(1, true, ST, __VA_ARGS__);                       \
-        else LAUNCH_BWD_WAVE_(1, false, ST, __VA_ARGS__);                           \
+        if (xexp) LAUNCH_BWD_WAVE_(true, ST, __VA_ARGS__);                          \
+        else LAUNCH_BWD_WAVE_(false, ST, __VA_ARGS__);                              \
     } while (0)
 #endif
 // (the row stride is a compile-time constant unless the launch handles one channel block of a wider feature)

@@ -112,7 +112,9 @@ _opts = _CallOptions()
 @contextlib.contextmanager
 def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None, exact_exp=None):
     """Within the block, forwards of this thread run with the given modes: `full_lists` materialises the reference's
-    point_list / full-list positions (parity tests), `f32_blend` selects the f32 FMA-chain forward for 32/64 channels, `no_cull` switches the exact-conservative cull off (testing aid), `fast_exp` evaluates exp() as
+    point_list / full-list positions (parity tests), `f32_blend` / `tile_fwd` select the f32 FMA-chain / tile-batched forwards for 32/64
+    channels (comparison kernels of the PROFILING build only -- MI_RAST_LIB=libmi_rast_prof.so; the product library refuses them with
+    MI_RAST_ERR_INVALID), `no_cull` switches the exact-conservative cull off (testing aid), `fast_exp` evaluates exp() as
     v_exp_f32(x * log2e) instead of the device library's expf the reference's kernels call (+2 % views/s, ~5 ulp: a few
     alpha >= 1/255 decisions differ from the reference's); `verify_lists` (debugging aid) checks that the count and emit passes of the
     lean lists agree slot by slot; `exact_exp` makes the forward blend call expf for every pair (product default: the hybrid form of
@@ -472,9 +474,15 @@ def _make_plain(channels):
 
     def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                             raster_settings):
+        # grad mode as the CALLER sees it (inside Function.forward it is always off): decides whether the forward leaves the backward's
+        # buffers zeroed (prezero).  Every entry point that reaches .apply must set it; it is put back afterwards so that a caller
+        # reaching .apply by another path never sees the value of somebody else's call (the backward fills for itself when in doubt).
         _opts.grad_mode = torch.is_grad_enabled()
-        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                         cov3Ds_precomp, raster_settings)
+        try:
+            return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                             cov3Ds_precomp, raster_settings)
+        finally:
+            _opts.grad_mode = True
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):

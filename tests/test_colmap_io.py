@@ -152,3 +152,26 @@ def test_load_3dgs_scene_applies_the_models_activations(tmp_path):
     np.testing.assert_array_equal(sc.shs[:, 0, :], np.stack([col[f"f_dc_{i}"] for i in range(3)], 1))
     np.testing.assert_array_equal(sc.shs[:, 1:, 0], np.stack([col[f"f_rest_{i}"] for i in range(15)], 1))   # channel-major on disk
     np.testing.assert_allclose(np.linalg.norm(sc.features, axis=1), 1.0, rtol=1e-5)
+
+
+def test_render_size_follows_the_image_file(tmp_path):
+    """The reference's loadCam takes `orig_w, orig_h` from the loaded image FILE (utils/camera_utils.py:21), not from the COLMAP camera
+    model: with `-i images_4` the render is a quarter of the model's size.  image_size_of reads that size from a PNG / JPEG header
+    (no image library), to_camera(image_size=) applies the resolution rule to it."""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 1297, 840, 8, 0, 0, 0, 0))
+           + chunk(b"IDAT", zlib.compress(b"\x00" * (1298 * 840))) + chunk(b"IEND", b""))
+    (tmp_path / "a.png").write_bytes(png)
+    jpg = (b"\xff\xd8" + b"\xff\xe0" + struct.pack(">H", 16) + b"JFIF\x00" + b"\x00" * 9 + b"\xff\xdb" + struct.pack(">H", 4) + b"\x00\x00"
+           + b"\xff\xc2" + struct.pack(">H", 11) + b"\x08" + struct.pack(">HH", 3361, 5187) + b"\x01\x01\x11\x00")
+    (tmp_path / "b.jpg").write_bytes(jpg)
+    assert colmap_io.image_size_of(str(tmp_path / "a.png")) == (1297, 840)
+    assert colmap_io.image_size_of(str(tmp_path / "b.jpg")) == (5187, 3361)
+    c = colmap_io.ColmapCamera(name="a.png", width=5187, height=3361, fovx=1.0, fovy=0.7, R=np.eye(3), T=np.zeros(3))
+    assert (colmap_io.to_camera(c).image_width, colmap_io.to_camera(c).image_height) == (1600, 1036)           # camera model, capped
+    cam = colmap_io.to_camera(c, image_size=(1297, 840))                                                       # images_4: as loaded
+    assert (cam.image_width, cam.image_height) == (1297, 840)

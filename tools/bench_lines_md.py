@@ -31,7 +31,7 @@ for name, cmd in runs:
         wv = r.get("whole_view") or {}
         t = d.get("timing") or {}
         summary.append(f"| `{cmd}` | {d['value']} | {(d.get('sustained') or {}).get('value')} | {d['ms_per_step']} | {t.get('ms_per_step_median')} ({t.get('ms_per_step_p10')}..{t.get('ms_per_step_p90')}) | "
-                       f"{r.get('kernel')}: {r.get('frac')} | {wv.get('frac')} / {wv.get('frac_without_replaced_stages')} / {wv.get('frac_traffic')} |")
+                       f"{r.get('kernel')}: {r.get('frac')} | {wv.get('frac')} / {wv.get('frac_survey_bytes')} / {wv.get('frac_traffic')} |")
         out += ["```json", js, "```", ""]
 out[3:3] = summary + [""]
 open(os.path.join(root, "profiles", f"{tag}_bench_lines.md"), "w").write("\n".join(out) + "\n")

@@ -1,4 +1,10 @@
-// blend_bwd_wave.h -- per-QUADRANT back-to-front gradient pass: one wave per 8x8 pixel quadrant, no workgroup barriers.
+// blend_bwd_wave_lab.h -- the LAB copy of seganygaussians_amd/csrc/blend_bwd_wave.h: the same kernel with the timing scaffolding and
+// the measured-and-rejected variants of rounds 3-4 still in it (MI_ABLATE masks, in-kernel phase timers, MI_BWD_DEFER, MI_BWD_SEPMOM,
+// MI_BWD_HYBRID_EXP, four quadrants per workgroup).  Compiled INSTEAD of the product header by the profiling build only
+// (-DMI_RAST_PROFILING: libmi_rast_prof.so, seganygaussians_amd/build.py; tools/bwd_table.sh, tools/ab.sh).  The product header
+// reads top to bottom without a preprocessor arm; keep the two in step when the product kernel changes.
+//
+// per-QUADRANT back-to-front gradient pass: one wave per 8x8 pixel quadrant, no workgroup barriers.
 //
 // Same mathematics and the same 16-row MFMA chunk as blend_bwd_mfma.h (renderCUDA<C> backward,
 // CF/cuda_rasterizer/backward.cu:399-559, with the three contractions S = F dL^T, dF = W^T dL, M = U^T Phi on
@@ -22,20 +28,46 @@
 
 #include <type_traits>
 
-#include "blend_bwd_shared.h"
-#include "blend_fwd.h"
-#include "common.h"
+#include "../../seganygaussians_amd/csrc/blend_bwd_shared.h"
+#include "../../seganygaussians_amd/csrc/blend_fwd.h"
+#include "../../seganygaussians_amd/csrc/common.h"
 
 namespace mirast {
 
 
+// ---- exp() of the backward ---------------------------------------------------------------------------------------------
+// The backward re-takes the forward's alpha >= 1/255 decisions, so near that cut it needs the forward's G bit for bit
+// (common.h: gauss_exp<true>, the device library's expf, 10 VALU).  Away from the cut it only needs G to a few ulp: every
+// use is a float-path quantity.  MI_BWD_HYBRID_EXP: G = v_exp_f32(power * log2e) (2 instructions; relative error
+// <= |power| * 1.5 * 2^-24 + 1 ulp <= 7e-7 wherever opacity * G can reach 1/255, i.e. power >= -5.55), and a group of
+// rows in which ANY lane's opacity * G lies within 1.5e-6 (relative) of 1/255 is re-evaluated with the exact form (a
+// wave-uniform branch, taken for ~1e-4 of the groups).  Outside that band both forms fall on the same side of the
+// cut: the decisions are the forward's, always.
+#ifndef MI_BWD_HYBRID_EXP
+#define MI_BWD_HYBRID_EXP 0
+#endif
+#ifndef MI_BWD_SEPMOM
+#define MI_BWD_SEPMOM 0
+#endif
+// MI_BWD_DEFER (round 4, A/B): the feature-gradient atomics of a full chunk are not issued in one burst behind its contractions but
+// spread over the NEXT chunk's scalar recurrences (one 16-row group of atomics behind every four rows), the chunk's dF block
+// waiting in registers (C / 4 VGPRs) and its Gaussian ids in LDS.  The waves of a CU run chunks of identical length; issued at the
+// chunk's end, their atomics arrive at the L2 atomic units (20 G segment-requests/s, tools/atomic_limit_probe.hip) in convoys.
+#ifndef MI_BWD_DEFER
+#define MI_BWD_DEFER 0
+#endif
 // 1 / x to ~0.5 ulp: v_rcp_f32 (1 ulp) plus one Newton step (two FMAs).  T is divided by (1 - alpha) once per row and the
 // quotients are chained through the whole list: the reference uses a correctly rounded division there (backward.cu:487).
+#ifndef MI_BWD_RCP_REFINE
+#define MI_BWD_RCP_REFINE 1
+#endif
 __device__ __forceinline__ float rcp_refined(float x)
 {
-    const float r = __builtin_amdgcn_rcpf(x);
-    return fmaf(fmaf(-x, r, 1.0f), r, r);
+    float r = __builtin_amdgcn_rcpf(x);
+    if (MI_BWD_RCP_REFINE) r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
 }
+constexpr float ALPHA_CUT_BAND = 1.5e-6f * ALPHA_CUT;
 // min(0.99, t) for t >= -1 as ONE instruction: v_med3_f32.  fminf() on a value that comes out of a select costs two (hipcc
 // canonicalises it first, v_max_f32 x, x, because the kernel runs in IEEE mode); the result is the same operand either way.
 __device__ __forceinline__ float alpha_clamp(float t) { return __builtin_amdgcn_fmed3f(t, 0.99f, -1.0f); }
@@ -51,9 +83,10 @@ struct BwvCfg {
 // C: channels as the MFMA tiling sees them (16, 32, 64); CR: channels in memory (CR == C; 3 for RGB padded to C = 16; 0: `cr_arg`
 // (1 .. 15) of a 16-channel block are real -- the last block of a feature whose width is no multiple of 16, the reference compiles
 // ANY NUM_CHANNELS (config_contrastive_f.h:15) -- with rows `cstride_arg` floats apart).
+// WPB: waves (quadrants) per workgroup, 1 or 4 -- the waves of a workgroup never synchronise either way.
 // STRIDED: rows of `colors` / `dL_dcolors` are `cstride_arg` floats apart (one channel block of a wider feature); otherwise CR.
-template <int C, int CR = C, bool MASKGRAD = false, bool XEXP = false, bool STRIDED = false>
-__global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
+template <int C, int CR = C, bool MASKGRAD = false, int WPB = 1, bool XEXP = false, bool STRIDED = false>
+__global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
     const uint32_t* __restrict__ tile_nsurv, int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ bg_color,
     const float* __restrict__ colors, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
@@ -62,7 +95,8 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     uint32_t* __restrict__ queue_ctr /* eight zeroed work-queue counters (common.h: xcd_grab) */,
     int cstride_arg /* STRIDED: floats between the rows of two Gaussians in `colors` and `dL_dcolors` = the full channel count of
                        the feature this launch handles one channel block of (both pointers then point at the block) */,
-    int cr_arg /* CR == 0: channels of this block that exist in memory */)
+    int cr_arg /* CR == 0: channels of this block that exist in memory */,
+    int ablate /* timing experiments: profiling build only (common.h: MI_ABLATE) */)
 {
     constexpr int FROW = BwvCfg<C>::FROW, QCAP = BwvCfg<C>::QCAP, FEAT4 = BwvCfg<C>::FEAT4;
     const int cstride = STRIDED ? cstride_arg : CR;   // (a compile-time constant in the common case: no 64-bit multiply, no extra registers)
@@ -71,18 +105,28 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     constexpr int NB = C / 16;   // 16-channel blocks of the dF contraction
     constexpr int F4 = C / 4;    // float4s per feature row
     constexpr int NK = (CHK * F4 + 63) / 64;  // float4 feature parts per lane and chunk
-    constexpr int MROW = 16;   // floats per row of the moment / field staging: 6 moments, then 8 fields
+    // floats per row of the moment / field staging.  MI_BWD_SEPMOM: 4 y-quarters x 12 slots of partial moments (then 8 fields);
+    // otherwise 6 moments (then 8 fields)
+    constexpr int MROW = MI_BWD_SEPMOM ? 48 : 16;
     static_assert(CR == C || (C == 16 && (CR == 3 || CR == 0)), "padded layouts: RGB, or a partial 16-channel block");
     static_assert(CR != 0 || STRIDED, "a partial block is a block of a wider (or narrower) feature: its row stride is an argument");
     static_assert(!MASKGRAD || CR == 3, "the mask gradient belongs to the RGB (DEPTH variant) kernel");
     static_assert(2 * CHK * WROW >= 64 * DLROW, "gradient-image staging must fit in the w/u rows");
 
-    __shared__ BwdPar s_par[CHK];                 // the chunk's 16 records
-    __shared__ float4 s_feat4[FEAT4];             // the chunk's 16 feature rows
-    __shared__ float4 s_wu4[2 * CHK * WROW / 4];  // S / w rows | u rows   (prologue: gradient-image staging; after step 3: moments)
-    __shared__ uint2 s_queue[QCAP];               // {walk index, entry = Gaussian id | quadrant mask << 28}
+    __shared__ BwdPar s_par_[WPB][CHK];            // the chunk's 16 records
+    __shared__ float4 s_feat4_[WPB][FEAT4];        // the chunk's 16 feature rows
+    __shared__ float4 s_wu4_[WPB][2 * CHK * WROW / 4];  // S / w rows | u rows   (prologue: gradient-image staging; after step 3: moments)
+    __shared__ uint2 s_queue_[WPB][QCAP];
+    __shared__ uint32_t s_pgid_[WPB][MI_BWD_DEFER ? CHK : 1];   // MI_BWD_DEFER: Gaussian ids of the chunk whose dF atomics are pending
+    const int wv = WPB == 1 ? 0 : (int)(threadIdx.x >> 6);
+    BwdPar* const s_par = s_par_[wv];
+    float4* const s_feat4 = s_feat4_[wv];
+    float4* const s_wu4 = s_wu4_[wv];
+    uint2* const s_queue = s_queue_[wv];
+    uint32_t* const s_pgid = s_pgid_[wv];
 
-    // One (tile, quadrant) item: everything below.  Which item a wave gets is decided at the end of the kernel.
+    // One (tile, quadrant) item: everything below.  With one wave per workgroup (the product) a wave works through items it
+    // takes from the queue of the XCD it runs on (see the end of the kernel).
     auto quadrant = [&](const uint32_t tile, const uint32_t quad) __attribute__((always_inline)) {
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
 
@@ -94,6 +138,11 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     const size_t HW = (size_t)H * W;
 
+    long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int n_chunks = 0, n_scans = 0;
+    const bool prof = MI_ABLATE(32);
+    long long tmark = prof ? clock64() : 0;
+#define TK(i) do { if (prof) { const long long t_ = clock64(); tk[i] += t_ - tmark; tmark = t_; } } while (0)
     const uint2 range = ranges[tile];
     const int NS_tile = (int)tile_nsurv[tile];
     const size_t pix_safe = inside ? pix_id : 0;
@@ -127,6 +176,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     uint32_t scan_reg = lst[max(0, NS - 1 - min(lane, NS - 1))];
     __builtin_amdgcn_sched_barrier(0);  // ... and the scan load behind the gradient-image staging
     float T = T_final;
+    TK(0);
 
     // ---- gradient image of this quadrant: one coalesced pass (lane = pixel), staged through LDS into the two MFMA
     // operand layouts.  The staging rows alias the w / u rows, which are first written in the chunk loop.
@@ -164,15 +214,23 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
     }
+    TK(1);
     if (NS == 0) return;
     const float nTb = -T_final * bg_dot_dpixel;  // the background term of dL/dalpha is nTb / (1 - alpha)
     const bool has_bg = ballot64(nTb != 0.f) != 0;   // wave-uniform
     const int last4 = last_contributor << 4;  // compared with (position << 4 | mask)
 
+    // MI_BWD_SEPMOM (default): the six moments are separable, x^a y^b.  Stage 1 contracts over x on the matrix pipe with
+    // v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks, K = 1, 8 cycles): block (row group rg = (lane >> 2) & 3, pixel row
+    // y = kq + 4 set) takes A = u[row 4 rg + (lane & 3)][pixel 8 y + t] and B = x_t^a with a = lane & 3 (a = 3: zero) for
+    // t = 0..7, and leaves X_a[row 4 rg + v][y] in register v of lane (rg, y, a): 16 MFMA x 8 cycles per chunk instead of
+    // 16 x 32 for M = U^T Phi with 6 of 16 columns in use.  Stage 2 (the sum over y with weights 1, y, y^2) is 20 VALU
+    // in-lane for the two sets plus a sum over the four y quarters by the row's lane when it reads the partials back.
+    // Otherwise:
     // Phi[pixel 16kq+s][j = n16] = monomial j (1, x, y, x^2, xy, y^2) about the quadrant centre, x = (s&7) - 3.5 (a
     // literal per unrolled step), y = 2kq - 3.5 + (s>>3):  phi = P[s>>3] + Q[s>>3] x + R x^2  (exact: small dyadics)
     float phP[2], phQ[2], phR;
-    {
+    if constexpr (!MI_BWD_SEPMOM) {
         const float c1 = n16 == 0, cx = n16 == 1, cy = n16 == 2, cxx = n16 == 3, cxy = n16 == 4, cyy = n16 == 5;
 #pragma unroll
         for (int v = 0; v < 2; v++) {
@@ -182,6 +240,9 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         }
         phR = cxx;
     }
+    // separable path: B_t = c0 + c1 x_t + c2 x_t^2 selects x_t^a for this lane's a = lane & 3; y of set 0 / set 1
+    const float sm_c0 = (lane & 3) == 0, sm_c1 = (lane & 3) == 1, sm_c2 = (lane & 3) == 2;
+    const float sm_y0 = (float)(lane >> 4) - 3.5f, sm_y1 = (float)(lane >> 4) + 0.5f;
 
     float Rcur = 0.f;  // sum over the Gaussians behind the current one of (their colour . dL) * their share of what is behind
     // wave-uniform constants, pinned to SGPRs (as VGPRs they get spilled, and a scratch reload in the middle of a chunk waits
@@ -213,6 +274,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg);
         qt += __builtin_popcountll(bal);
         scanned += 64;
+        if (prof) n_scans++;
         scan_reg = lst[NS - 1 - min(scanned + lane, NS - 1)];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
@@ -252,14 +314,43 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     int nrows = min(CHK, qt - qh);
     if (nrows == 0) return;
     request_rows(nrows);
+    TK(2);
 
     // One chunk: stage the requested rows, request the next chunk's rows, process.  Called once before the loop and once
     // inside it (always inlined): hipcc computes the vmcnt wait for the staged rows from the FEWEST memory operations any
     // path issues behind their loads; with the first chunk peeled off, every path into the loop's copy has issued the
     // previous chunk's atomics (a fixed number) behind them, so the wait leaves those in flight.
     int nnext = 0;
-    auto do_chunk = [&](auto full_tag) __attribute__((always_inline)) {
+    // MI_BWD_DEFER: dF block of the previous full chunk (lane (n16, kq): channel 16 nb + n16 of rows 4 kq + r), not yet added
+    v4f pend[NB];
+    bool have_pend = false;   // wave-uniform
+    // (`sure`: the caller knows a block is pending -- every chunk of the loop below; a run-time test there would let hipcc
+    // compute the vmcnt wait for the staged rows from the path WITHOUT these atomics, i.e. wait for them)
+    auto flush_pend = [&](const int r, const bool sure) __attribute__((always_inline)) {   // rows 4 kq + r of the pending chunk
+        if constexpr (MI_BWD_DEFER) {
+            if (sure || have_pend) {
+                const uint32_t gid = s_pgid[4 * kq + r];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const int ch = 16 * nb + n16;
+                    if constexpr (CR == C) {
+                        atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], pend[nb][r]);
+                    } else {
+                        if (ch < cr) atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], pend[nb][r]);
+                        else if (MASKGRAD && ch == CR) atomicAdd(&gpack[(size_t)gid * 8 + 6], pend[nb][r]);
+                    }
+                }
+            }
+        }
+    };
+    auto do_chunk = [&](auto full_tag, auto pend_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;   // all 16 rows are real: no padding, unconditional atomics
+        constexpr bool PEND = decltype(pend_tag)::value;   // MI_BWD_DEFER: the previous chunk's dF block is pending (FULL chunks)
+        if constexpr (MI_BWD_DEFER && !FULL) {   // the wave's last chunk: nothing to hide the pending atomics behind
+#pragma unroll
+            for (int r = 0; r < 4; r++) flush_pend(r, false);
+            have_pend = false;
+        }
         // ---- 1. the chunk's rows: registers -> LDS.  Rows beyond nrows (the wave's last chunk only) become padding
         // records: never valid (position 0x7ffffff), zero features, opacity 1; their atomics are masked off (adding their
         // exact zeros to some real row instead costs dearly: same-address atomics serialise at ~22 ns each).
@@ -293,6 +384,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             }
         }
         qh += nrows;
+        TK(3);
         // ---- 2. keep the queue ahead of the chunks (one scan block per chunk while there is room), then request the
         // next chunk's rows: everything below runs while they travel
         if (scanned < NS && qt - qh <= QCAP - 64) consume_scan();
@@ -300,6 +392,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         nnext = min(CHK, qt - qh);
         if (nnext > 0) request_rows(nnext);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        TK(4);
 
         // ---- 3. S = F . dL^T  (16 rows x 64 pixels, K = C channels); lane (n16, kq) feeds row n16
         v4f sacc[4];
@@ -329,6 +422,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) my_wa[(4 * kq + r) * WROW + 16 * pb + n16] = sacc[pb][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        TK(5);
 
         // ---- 4. scalar recurrences (lane = pixel), back to front.  Row parameters arrive by LDS broadcast reads.
         // A row that does not blend into this pixel runs the same arithmetic with alpha = 0: T, R stay put, w = u = 0.
@@ -340,7 +434,13 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             const bool can = (__float_as_int(p1.z) < last4) && power <= 0.0f;
             // opacity * G where the row can blend into this pixel at all, else 0; the 1/255 cut is the last test
             // (min(0.99, t) >= 1/255  <=>  t >= 1/255)
-            const float t0 = can ? p1.y * gauss_exp<XEXP>(power) : 0.f;
+            float t0;
+            if constexpr (XEXP && MI_BWD_HYBRID_EXP) {
+                t0 = can ? p1.y * gauss_exp_fast(power) : 0.f;
+                if (ballot64(fabsf(t0 - ALPHA_CUT) <= ALPHA_CUT_BAND) != 0) t0 = can ? p1.y * gauss_exp<true>(power) : 0.f;
+            } else {
+                t0 = can ? p1.y * gauss_exp<XEXP>(power) : 0.f;
+            }
             const float tG = t0 >= ALPHA_CUT ? t0 : 0.f;   // opacity * G of a contributing row
             const float alpha = alpha_clamp(tG);
             const float om = 1.f - alpha;
@@ -359,6 +459,8 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         // row's own reciprocal): bg = 0 is SAGA's feature training (train_contrastive_feature.py:98).
         auto row_group4 = [&](const int r0) __attribute__((always_inline)) {
             float tG[4], al[4], om[4];
+            constexpr bool HYB = XEXP && MI_BWD_HYBRID_EXP;
+            bool band = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int rr = r0 + k;
@@ -366,9 +468,24 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
                 const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
                 const float dx = p0.x - pixfx, dy = p0.y - pixfy;
                 const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-                const float G = gauss_exp<XEXP>(power);
+                const float G = HYB ? gauss_exp_fast(power) : gauss_exp<XEXP>(power);
                 const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;
+                if constexpr (HYB) band = band || fabsf(t0 - ALPHA_CUT) <= ALPHA_CUT_BAND;
                 tG[k] = t0 >= ALPHA_CUT ? t0 : 0.f;
+            }
+            if constexpr (HYB) {
+                if (ballot64(band) != 0) {  // some lane sits on the cut: the forward's own exp decides (rare; rows re-read from LDS)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int rr = r0 + k;
+                        const float4 p0 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar));
+                        const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
+                        const float dx = p0.x - pixfx, dy = p0.y - pixfy;
+                        const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
+                        const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * gauss_exp<true>(power) : 0.f;
+                        tG[k] = t0 >= ALPHA_CUT ? t0 : 0.f;
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -391,7 +508,20 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             }
         };
         if constexpr (FULL) {  // straight-line code for the full chunk: the 16 rows' LDS reads overlap each other's arithmetic
-            if (has_bg) {
+            if constexpr (PEND) {
+                // (the pending atomics at the JOIN of the two forms of a four-row group: inside the arms, hipcc's structurizer leaves
+                // a path around one arm -- exec == 0, never taken -- and the vmcnt wait for the staged rows is computed from it)
+#pragma unroll
+                for (int r0 = 0; r0 < CHK; r0 += 4) {
+                    if (has_bg) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) row_step(r0 + k);
+                    } else {
+                        row_group4(r0);
+                    }
+                    flush_pend(r0 >> 2, true);
+                }
+            } else if (has_bg) {
 #pragma unroll
                 for (int rr = 0; rr < CHK; rr++) row_step(rr);
             } else {
@@ -406,47 +536,91 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        TK(6);
 
         // ---- 5. dF = W^T . dL  and  M = U^T . Phi   (A rows from LDS, lane (m = n16, kq) reads pixels 16kq..16kq+15)
         v4f facc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) facc[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
         v4f macc = (v4f){0.f, 0.f, 0.f, 0.f};
+        v4f xacc0 = (v4f){0.f, 0.f, 0.f, 0.f}, xacc1 = (v4f){0.f, 0.f, 0.f, 0.f};  // MI_BWD_SEPMOM: X_a[row][y] of set 0 / set 1
         {
             const float4* wrow = reinterpret_cast<const float4*>(my_wa + n16 * WROW + 16 * kq);
             const float4* urow = reinterpret_cast<const float4*>(my_ua + n16 * WROW + 16 * kq);
+            // separable moments: this lane's row is 4 rg + (lane & 3) = n16, its pixel rows kq and kq + 4
+            const float4* urow_s0 = reinterpret_cast<const float4*>(my_ua + n16 * WROW + 8 * kq);
+            const float4* urow_s1 = reinterpret_cast<const float4*>(my_ua + n16 * WROW + 8 * kq + 32);
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
                 const float4 wv = wrow[s4];
                 const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
-                const float4 uv = urow[s4];
-                const float ua[4] = {uv.x, uv.y, uv.z, uv.w};
+                float ua[4], ub[4];
+                if constexpr (MI_BWD_SEPMOM) {
+                    if (s4 < 2) {  // pixels 4 s4 .. 4 s4 + 3 of the lane's two pixel rows
+                        const float4 u0 = urow_s0[s4], u1 = urow_s1[s4];
+                        ua[0] = u0.x, ua[1] = u0.y, ua[2] = u0.z, ua[3] = u0.w;
+                        ub[0] = u1.x, ub[1] = u1.y, ub[2] = u1.z, ub[3] = u1.w;
+                    }
+                } else {
+                    const float4 uv = urow[s4];
+                    ua[0] = uv.x, ua[1] = uv.y, ua[2] = uv.z, ua[3] = uv.w;
+                }
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     const int s = 4 * s4 + t;
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++)
                         facc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[nb][s], facc[nb], 0, 0, 0);
-                    const float x = (float)(s & 7) - 3.5f;
-                    const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
-                    macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
+                    if constexpr (MI_BWD_SEPMOM) {
+                        if (s4 < 2) {
+                            const float x = (float)s - 3.5f;  // s = 0..7: the pixel column
+                            const float xa = fmaf(x, fmaf(x, sm_c2, sm_c1), sm_c0);
+                            xacc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ua[t], xa, xacc0, 0, 0, 0);
+                            xacc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(ub[t], xa, xacc1, 0, 0, 0);
+                        }
+                    } else {
+                        const float x = (float)(s & 7) - 3.5f;
+                        const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
+                        macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
+                    }
                 }
             }
         }
+        TK(7);
         // ---- 6. outputs.  Result layout: lane l holds column n16 of rows 4*kq + r.  Every atomic below is issued
         // unconditionally (see the header): rows that contributed nothing add exact zeros.
         const BwdPar mine = *reinterpret_cast<const BwdPar*>(par_bytes + n16 * (int)sizeof(BwdPar));  // lane n16 = row n16
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the MFMA operand reads of the w rows are done: moments may land there
+        constexpr bool DEFER = MI_BWD_DEFER && FULL;
+        if constexpr (DEFER) {   // the next chunk adds this block (or the flush behind the last chunk does)
+            if (lane < CHK) s_pgid[lane] = __float_as_uint(mine.q1.w);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+            for (int nb = 0; nb < NB; nb++) pend[nb] = facc[nb];
+            have_pend = true;
+        }
+#pragma unroll
+        for (int r = 0; r < (DEFER ? 0 : 4); r++) {
             const int row = 4 * kq + r;
             // the row's Gaussian id, straight from the staged record (a __shfl would keep its lane arithmetic alive
             // across the whole kernel -- and spilled)
-            const uint32_t gid = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row * (int)sizeof(BwdPar) + 28));
+            uint32_t gid = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row * (int)sizeof(BwdPar) + 28));
+#ifdef MI_RAST_PROFILING
+            // timing experiments on the atomics (wrong results): 8192 = every quadrant adds to rows of its own (no line is shared
+            // by the quadrants of a tile); 16384 = only the lowest quadrant of a record's mask adds (the request count a perfect
+            // (tile, record) reduction would leave)
+            const uint32_t pm_row = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row * (int)sizeof(BwdPar) + 24));
+            if (MI_ABLATE(8192)) gid = (gid + quad * 250007u) % 1000000u;
+            const bool lowest_q = ((pm_row & 15u) & (0u - (pm_row & 15u))) == (1u << quad);
+#endif
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
                 const int ch = 16 * nb + n16;
+                if (MI_ABLATE(64)) continue;
                 if (!FULL && row >= nrows) continue;
+#ifdef MI_RAST_PROFILING
+                if (MI_ABLATE(16384) && !lowest_q) continue;
+#endif
+                if (MI_ABLATE(512)) { dL_dcolors[(size_t)gid * cstride + ch] = facc[nb][r]; continue; }  // plain stores instead of atomics (wrong results)
                 if constexpr (CR == C) {
                     atomicAdd(&dL_dcolors[(size_t)gid * cstride + ch], facc[nb][r]);
                 } else {
@@ -457,17 +631,43 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         }
         // (a separate, unconditional loop: with the store inside the loop above and guarded by n16 < 8, hipcc clones the
         // atomics into both arms of the guard -- twice the memory instructions, and a count that depends on the path)
+        if constexpr (MI_BWD_SEPMOM) {
+            // stage 2: Z_b = y0^b X(set 0) + y1^b X(set 1), b = 0, 1, 2, for the four rows 4 rg + v this lane holds, stored at
+            // slot 3 a + b of the (row, y quarter) group of 12 floats: {M0, M2 (y), M5 (y^2)} {M1 (x), M4 (xy), -} {M3 (x^2), -, -} {-, -, -}
+            int l = threadIdx.x & 63;
+            asm volatile("" : "+v"(l));  // (per-chunk address arithmetic: hoisted out of the chunk loop it would be spilled)
+            float* const mbase = my_mom + ((l >> 2) & 3) * (4 * MROW) + 12 * (l >> 4) + 3 * (l & 3);
+            const float y0 = sm_y0, y1 = sm_y1, y0q = sm_y0 * sm_y0, y1q = sm_y1 * sm_y1;
 #pragma unroll
-        for (int r = 0; r < 4; r++) my_mom[(4 * kq + r) * MROW + n16] = macc[r];
+            for (int v = 0; v < 4; v++) {
+                mbase[v * MROW + 0] = xacc0[v] + xacc1[v];
+                mbase[v * MROW + 1] = fmaf(y1, xacc1[v], y0 * xacc0[v]);
+                mbase[v * MROW + 2] = fmaf(y1q, xacc1[v], y0q * xacc0[v]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) my_mom[(4 * kq + r) * MROW + n16] = macc[r];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // moments -> fields: lane = row (16 lanes) rewrites its my_mom row in place, then the wave adds the rows
         // to the packed per-Gaussian records: lane -> (row = l / 8 (+8), field = l % 8), 32 contiguous bytes per row
         {
             if (lane < 16) {
                 const int row = lane;
-                const float4 m0 = reinterpret_cast<const float4*>(my_mom + row * MROW)[0];
-                const float4 m1 = reinterpret_cast<const float4*>(my_mom + row * MROW)[1];
-                const float M0 = m0.x, M1 = m0.y, M2 = m0.z, M3 = m0.w, M4 = m1.x, M5 = m1.y;
+                float4 m0 = reinterpret_cast<const float4*>(my_mom + row * MROW)[0];
+                float4 m1 = reinterpret_cast<const float4*>(my_mom + row * MROW)[1];
+                float M0, M1, M2, M3, M4, M5;
+                if constexpr (MI_BWD_SEPMOM) {  // sum over the four y quarters; slots {M0, M2, M5, M1} {M4, -, M3, -}
+#pragma unroll
+                    for (int q = 1; q < 4; q++) {
+                        const float4 a0 = reinterpret_cast<const float4*>(my_mom + row * MROW)[3 * q];
+                        const float4 a1 = reinterpret_cast<const float4*>(my_mom + row * MROW)[3 * q + 1];
+                        m0.x += a0.x, m0.y += a0.y, m0.z += a0.z, m0.w += a0.w, m1.x += a1.x, m1.z += a1.z;
+                    }
+                    M0 = m0.x, M2 = m0.y, M5 = m0.z, M1 = m0.w, M4 = m1.x, M3 = m1.z;
+                } else {
+                    M0 = m0.x, M1 = m0.y, M2 = m0.z, M3 = m0.w, M4 = m1.x, M5 = m1.y;
+                }
                 const float ca = -2.f * mine.q0.z, cb = -mine.q0.w, cc = -2.f * mine.q1.x, op = mine.q1.y;
                 const float gx = mine.q0.x - cxq, gy = mine.q0.y - cyq;
                 // dx = gx - x', dy = gy - y'
@@ -492,27 +692,65 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const int row2 = 8 * it + (lane >> 3), f = lane & 7;
-                const uint32_t gid2 = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row2 * (int)sizeof(BwdPar) + 28));
-                if (FULL || row2 < nrows) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * MROW + f]);   // fields 6, 7 receive +0
+                uint32_t gid2 = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row2 * (int)sizeof(BwdPar) + 28));
+#ifdef MI_RAST_PROFILING
+                const uint32_t pm_row2 = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row2 * (int)sizeof(BwdPar) + 24));
+                if (MI_ABLATE(8192)) gid2 = (gid2 + quad * 250007u) % 1000000u;
+                if (MI_ABLATE(16384) && ((pm_row2 & 15u) & (0u - (pm_row2 & 15u))) != (1u << quad)) continue;
+#endif
+                if (MI_ABLATE(512)) { gpack[(size_t)gid2 * 8 + f] = my_mom[row2 * MROW + f]; continue; }
+                if (!MI_ABLATE(128) && (FULL || row2 < nrows)) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * MROW + f]);   // fields 6, 7 receive +0
             }
         }
+        TK(8);
+        if (prof) n_chunks++;
     };
     // Full chunks: the first one peeled off, the rest in a loop whose every iteration issues the same memory instructions.
     // The wave's last, partial chunk runs a third copy with padding rows and predicated atomics (nothing is staged behind it).
     if (nrows == CHK) {
-        do_chunk(std::true_type{});
-        while (nnext == CHK) {
-            nrows = nnext;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // moment reads before the next chunk's S rows land there
-            do_chunk(std::true_type{});
+        do_chunk(std::true_type{}, std::false_type{});
+        if constexpr (MI_BWD_DEFER) {
+            // the second chunk peeled off as well, the loop INSIDE its branch: only then has every path into the loop's copy issued
+            // the same memory instructions (8 deferred feature atomics + 2 geometry atomics) behind the staged rows' loads, and the
+            // wait for those rows leaves all ten in flight (reachable from the first chunk -- 2 atomics behind its loads -- hipcc
+            // emits vmcnt(4) at the loop head: six atomics drained per chunk)
+            if (nnext == CHK) {
+                nrows = nnext;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                do_chunk(std::true_type{}, std::true_type{});
+                while (nnext == CHK) {
+                    nrows = nnext;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    do_chunk(std::true_type{}, std::true_type{});
+                }
+            }
+        } else {
+            while (nnext == CHK) {
+                nrows = nnext;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // moment reads before the next chunk's S rows land there
+                do_chunk(std::true_type{}, std::false_type{});
+            }
         }
         nrows = nnext;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    if (nrows != 0) do_chunk(std::false_type{});
+    if (nrows != 0) do_chunk(std::false_type{}, std::false_type{});
+    if constexpr (MI_BWD_DEFER) {
+        if (have_pend) {   // no partial chunk behind the last full one
+#pragma unroll
+            for (int r = 0; r < 4; r++) flush_pend(r, false);
+        }
+    }
+    if (prof && lane == 0) {
+        for (int i = 0; i < 9; i++) atomicAdd(&gpack[8 * (i + 1) + 7], (float)tk[i]);
+        atomicAdd(&gpack[8 * 10 + 7], (float)n_chunks);
+        atomicAdd(&gpack[8 * 11 + 7], (float)n_scans);
+        atomicAdd(&gpack[8 * 12 + 7], 1.f);
+    }
+#undef TK
     };
 
-    {
+    if (WPB == 1) {
         // workgroup -> (tile, quadrant).  Every XCD works through a contiguous run of tiles (common.h), and the four
         // quadrants of a tile go to four of its waves at about the same time: the records, the feature rows and the gradient
         // lines that the quadrants of a tile AND neighbouring tiles share stay in one L2.  The first half of a run
@@ -530,6 +768,8 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             item = xcd_grab(queue_ctr, ntiles, 4u);
         }
         if (item != 0xFFFFFFFFu) quadrant(item >> 2, item & 3u);
+    } else if (blockIdx.x < ntiles) {
+        quadrant(blockIdx.x, (uint32_t)(threadIdx.x >> 6));
     }
 }
 
