@@ -130,11 +130,6 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override Gaussian count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--rs-ag", action="store_true",
-                    help="N > 1: exchange the feature gradients as reduce-scatter -> rank-local feature update (plain SGD, lr "
-                         "--rs-ag-lr, on this rank's 1/N of the rows) -> all-gather of the updated rows (dist.sharded_update_async) "
-                         "instead of one all-reduce; the next view's blend stage waits for the all-gather only")
-    ap.add_argument("--rs-ag-lr", type=float, default=1e-4)
     ap.add_argument("--dist-single", action="store_true",
                     help="testing only: initialise torch.distributed (RCCL) with a single rank and run the N > 1 step")
     ap.add_argument("--settle", type=float, default=3.0,
@@ -192,7 +187,7 @@ def main():
                      f"MI_RAST_LIB={_build.PROF_LIB_PATH} python bench.py --tile-fwd ...  (python -m seganygaussians_amd.build --profiling builds it)")
     install_dropin()
     from seganygaussians_amd import rasterizer as R
-    from seganygaussians_amd.dist import allreduce_grads_async, sharded_update_async
+    from seganygaussians_amd.dist import allreduce_grads_async
 
     cfg = scenes.CONFIGS[args.config]
     C, W, H = cfg["C"], cfg["W"], cfg["H"]
@@ -288,13 +283,7 @@ def main():
         if dist is not None and not state.get("solo"):
             # sum the per-Gaussian feature gradients of the N views over RCCL/xGMI: one flat 128-MB bucket, asynchronous
             # (not in rank 0's reporting-only steps behind the timed regions: a collective only one rank enters never completes)
-            if args.rs_ag:
-                # reduce-scatter -> this rank updates its 1/N of the feature rows -> all-gather of the updated rows: the same bytes
-                # on the wire, but only the all-gather (and an optimizer pass over 1/N of the rows) in front of the next blend
-                lr = args.rs_ag_lr
-                state["pending"] = sharded_update_async(feats, feats.grad, lambda prow, grow, lo, hi: prow.add_(grow, alpha=-lr))
-            else:
-                state["pending"] = allreduce_grads_async([feats.grad])
+            state["pending"] = allreduce_grads_async([feats.grad])
         state.update(radii=radii, color=color.detach(), means2D=means2D)
 
     def barrier():
@@ -618,7 +607,7 @@ def main():
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "sustained": sustained, "timing": timing, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": data,
-            "config": {"workload": what, "parallelism": f"view-sharded x{world}" + (" rs-ag" if args.rs_ag and world > 1 else ""), "counters": counters,
+            "config": {"workload": what, "parallelism": f"view-sharded x{world}", "counters": counters,
                        "lists": "lean (product default: only overlaps that pass the exact-conservative cull are listed; "
                                 "counters E/L from one full-list call)",
                        "arithmetic": "f32 throughout; C=32/64 forward accumulation = exact 3-way bf16 split of f32 operands, "
@@ -634,17 +623,11 @@ def main():
     phase("reporting")
     state["solo"] = False
     if args.dump_grads and not fwd_only:
-        os.makedirs(args.dump_grads, exist_ok=True)
-        barrier()
-        if args.rs_ag:   # the features this step starts from (updated by every step so far: the same on every rank)
-            np.save(os.path.join(args.dump_grads, f"features_before_rank{rank}.npy"), feats.detach().cpu().numpy())
         step()
-        barrier()   # waits for this step's exchange: feats.grad holds the sum over the ranks' views (all-reduce) / feats the update (--rs-ag)
+        barrier()   # waits for this step's all-reduce: feats.grad now holds the sum over the ranks' views
+        os.makedirs(args.dump_grads, exist_ok=True)
         np.save(os.path.join(args.dump_grads, f"camera_{rank}.npy"), np.concatenate([cam.viewmatrix.ravel(), cam.projmatrix.ravel()]))
-        if args.rs_ag:   # every rank: its LOCAL gradient (the sum only ever exists in shards) and the features after the sharded update
-            np.save(os.path.join(args.dump_grads, f"feature_grad_local_rank{rank}.npy"), feats.grad.detach().cpu().numpy())
-            np.save(os.path.join(args.dump_grads, f"features_rank{rank}.npy"), feats.detach().cpu().numpy())
-        elif rank == 0:
+        if rank == 0:
             np.save(os.path.join(args.dump_grads, "feature_grad_rank0.npy"), feats.grad.detach().cpu().numpy())
     if dist is not None:
         dist.destroy_process_group()

