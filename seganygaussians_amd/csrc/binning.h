@@ -104,10 +104,8 @@ constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 constexpr int BIN_MAX_WG = 256;        // workgroups of the count / emit passes (rank slices): one per CU, all resident at once
                                        // (measured 512 / 256 / 128 / 64 slices on cfg3: count + emit 0.167 / 0.146 / 0.199 / 0.349 ms)
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_TILES = 15 * 1024 - 128;  // per launch of the count / emit passes: one LDS cursor per tile + the hand-off arrays and
-                                                // the emit pass's step-sort buffers (EMIT_LDS_WORDS: 100 KB) must fit in 160 KB; larger
-                                                // images are walked in bands of tile rows.  Also < STEP_NOKEY: a tile's index in its band is
-                                                // a 15-bit sort key
+constexpr int BIN_MAX_TILES = 26 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 57 KB of hand-off
+                                               // arrays must fit in 160 KB; larger images are walked in bands of tile rows
 constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
 
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const uint32_t* __restrict__ tile_total,
@@ -382,34 +380,19 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
 }
 
 // ---- lean lists from row spans (the product default) ------------------------------------------------------------
-// The count and emit passes of the lean lists without a single per-tile test -- and, since round 5, WITHOUT A PER-TILE SORT behind
-// them: the emit pass stores every list entry at its final, depth-ordered position.
-//
-// Slices.  The rank axis is cut into gridDim.x CONTIGUOUS slices of equal work (slice_rank_range: boundaries at depth-bucket
-// boundaries, weights from the depth sort), slice s counted and emitted by one workgroup, and a tile's segment is the
-// concatenation of the slices' shares in slice order (partial[][], scan_partials_kernel, as before).  Inside a slice the workgroup
-// walks ROUNDS of 1024 consecutive ranks; the items of a round -- (Gaussian, tile row) pairs, then the tiles of their spans -- are
-// enumerated in (rank, row, column) order, balanced over the workgroup as before.  So if every STEP of the enumeration hands out
-// the list slots of a tile in the order of the enumeration, a tile's list comes out ordered by rank: ordering by rank is ordering
-// by (depth bits, Gaussian index), the reference's order (rasterizer_impl.cu:70-113, 296-308).
-//   COUNT (EMIT = false): +1 / -1 at the two ends of each row span in a per-row difference grid in LDS; the prefix along x is
+// The count and emit passes of the lean lists without a single per-tile test.  Items of the first level are (Gaussian,
+// tile row) pairs, balanced over the workgroup like the tiles of bin_ranks_kernel (a Gaussian covers 1 .. 68 rows); each
+// evaluates the two closed-form column intervals of its row's upper and lower 8-pixel band (cull.h: band_columns) and
+// gets the tile span [x0, x1) that holds them.
+//   COUNT (EMIT = false): +1 / -1 at the two ends of the span in a per-row difference grid in LDS; the prefix along x is
 //                the number of spans covering each tile -- this slice's share of the tile's segment, EXACTLY: a tile is
 //                counted iff the emit pass stores an entry for it, so the segments have no unused slots;
-//   EMIT:        second level, the tiles of the spans of a window in steps of STEP_ITEMS: the quadrant mask of a tile is read off
-//                the two column intervals (four range tests on integers); the step's (tile, item) pairs are sorted by tile in LDS
-//                -- two stable 8-bit radix passes (radix_pass below) --, every run of equal tiles takes its slots from the tile's
-//                LDS cursor in one piece (no atomics: one run per tile and step), and the entry is stored in its final form
-//                Gaussian id | quadrant mask << 28.  (Rounds 1-4: arrival order by LDS atomics, then a radix sort of every tile's
-//                segment in a kernel of its own: 67 us on cfg3, 291 us on cfg5 -- gone; the step sort costs the emit pass
-//                ~ 13 workgroup barriers per 2048 entries.)
+//   EMIT:        second level, the tiles of the 1024 spans of a window, balanced again: the quadrant mask of a tile is read
+//                off the two column intervals (four range tests on integers), the slot comes from the LDS cursor.
 // Measured on cfg3: 8.68 M tiles in the shrunk rects, 5.2 M in the spans; the enumerating emit pass spent 182 VALU
 // instructions per 64 rect tiles on the whole-tile test and 386 per 64 survivors on the four quadrant tests.
-constexpr int SLICE_NB = 16 * 1024;   // depth buckets the slice boundaries are chosen from (== depth_sort.h: DS_NB)
-constexpr int STEP_ITEMS = 2048;      // tiles per step of the emit pass: two per thread
-constexpr uint32_t STEP_NOKEY = 0x7FFFu;   // sort key of an item without an entry (sorts behind every tile of the band)
+// Slices (rank chunks dealt round robin), partial[][] and the cursors are those of bin_count_kernel / bin_ranks_kernel.
 constexpr int SPAN_LDS_WORDS = 3088 + 2048 + 4096 + 5 * 1024;  // RectWork + means + conics + prefix / rect / tau-free params
-// EMIT: + Gaussian ids [1024], payloads [STEP_ITEMS], two sort buffers [STEP_ITEMS], histograms [16][256], a few words
-constexpr int EMIT_LDS_WORDS = SPAN_LDS_WORDS + 1024 + 3 * STEP_ITEMS + 16 * 256 + 64;
 
 __device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid, uint32_t* s_wsum, uint32_t& total)
 {
@@ -429,85 +412,15 @@ __device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid
     return incl + woff;
 }
 
-// Ranks [begin, end) of slice `slice` of `nslices`: the rank axis cut at depth-bucket boundaries into pieces of equal work.
-// bucket_work[b] (depth_sort.h: sum over the bucket's Gaussians of tiles + 8) and bucket_ranges[b] (the bucket's ranks; {0, 0} when
-// empty) are what the depth sort left.  With W(b) := the work in front of bucket b, boundary s is the end of the LAST bucket b with
-// W(b) < ceil(s W_total / nslices) -- a non-empty bucket by construction --, or rank 0.  Every workgroup of the count AND of the
-// emit pass evaluates this for its own slice from the same integers: the slices partition [0, V) and both passes agree on them.
-// Contains workgroup barriers: call from all 1024 threads; s_tmp: 48 words of LDS.
-__device__ __forceinline__ void slice_rank_range(const uint32_t* __restrict__ bucket_work, const uint2* __restrict__ bucket_ranges,
-                                                 uint32_t slice, uint32_t nslices, int tid, uint32_t* s_tmp, uint32_t& begin,
-                                                 uint32_t& end)
-{
-    static_assert(SLICE_NB == 16 * BIN_THREADS, "sixteen buckets per thread");
-    const int lane = tid & 63, wave = tid >> 6;
-    uint32_t w[16];
-    const uint4* src = reinterpret_cast<const uint4*>(bucket_work + 16 * tid);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint4 v = src[q];
-        w[4 * q + 0] = v.x;
-        w[4 * q + 1] = v.y;
-        w[4 * q + 2] = v.z;
-        w[4 * q + 3] = v.w;
-    }
-    uint32_t sum = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) sum += w[j];
-    const uint32_t incl = wave_inclusive_scan(sum, lane);
-    if (lane == 63) s_tmp[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t c = s_tmp[k];
-        woff += k < wave ? c : 0u;
-        total += c;
-    }
-    const uint32_t need0 = (uint32_t)(((uint64_t)slice * total + nslices - 1u) / nslices);
-    const uint32_t need1 = (uint32_t)(((uint64_t)(slice + 1u) * total + nslices - 1u) / nslices);
-    uint32_t run = woff + incl - sum, c0 = 0, c1 = 0;   // buckets of mine with W(b) < need
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        c0 += run < need0 ? 1u : 0u;
-        c1 += run < need1 ? 1u : 0u;
-        run += w[j];
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        c0 += (uint32_t)__shfl_xor((int)c0, o, 64);
-        c1 += (uint32_t)__shfl_xor((int)c1, o, 64);
-    }
-    if (lane == 0) {
-        s_tmp[16 + wave] = c0;
-        s_tmp[32 + wave] = c1;
-    }
-    __syncthreads();
-    uint32_t b0 = 0, b1 = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        b0 += s_tmp[16 + k];
-        b1 += s_tmp[32 + k];
-    }
-    begin = b0 ? bucket_ranges[b0 - 1u].y : 0u;
-    end = b1 ? bucket_ranges[b1 - 1u].y : 0u;
-    __syncthreads();  // s_tmp is the caller's again
-}
-
-template <int NW, int MAXB, typename SrcPtr, typename DstPtr>
-__device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int shift, uint32_t (*s_hist)[256], int tid);
-
 template <bool EMIT>
 __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const BlendRec* __restrict__ rank_rec,
                                                                 uint32_t* __restrict__ partial,
                                                                 const uint2* __restrict__ ranges,
-                                                                uint32_t* __restrict__ blend_list, uint32_t gx, uint32_t gy_all,
-                                                                uint32_t by0, uint32_t by1,
-                                                                const uint32_t* __restrict__ bucket_work,
-                                                                const uint2* __restrict__ bucket_ranges, int ablate)
+                                                                uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy_all,
+                                                                uint32_t by0, uint32_t by1, int ablate)
 {
     // COUNT: s_dyn = difference grid [band rows][stride] (ints), then the hand-off arrays
-    // EMIT : s_dyn = cursors [band tiles], then the hand-off arrays, then the step sort's buffers
+    // EMIT : s_dyn = cursors [band tiles], then the hand-off arrays
     extern __shared__ uint32_t s_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t gy = by1 - by0;
@@ -527,35 +440,25 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
     uint32_t* s_grad = s_grect + 1024;       // radius (the margin of tau needs it)
     uint32_t* s_q0 = s_grad + 1024;          // EMIT, per span: upper band's columns lo | hi << 11, Gaussian slot << 22
     uint32_t* s_q1 = s_q0 + 1024;            //                 lower band's columns lo | hi << 11
-    uint32_t* s_gid = s_q1 + 1024;           // EMIT: the round's Gaussian ids
-    uint32_t* s_pay = s_gid + 1024;          // EMIT: the step's entries (id | quadrant mask << 28) by item slot
-    uint32_t* s_sa = s_pay + STEP_ITEMS;     // EMIT: the step's sort words (tile key << 11 | item slot), ping ...
-    uint32_t* s_sb = s_sa + STEP_ITEMS;      //       ... pong
-    uint32_t (*s_hist)[256] = reinterpret_cast<uint32_t (*)[256]>(s_sb + STEP_ITEMS);
-    uint32_t* s_misc = s_sb + STEP_ITEMS + 16 * 256;   // [64]
-    // workgroup b works on slice slice_row(b): the slices of one XCD (b % 8) are neighbours on the rank axis and in every tile's
-    // segment, so the 4-byte entries sharing a 128-byte line are mostly stored from ONE XCD
-    const uint32_t slice = slice_row(blockIdx.x, gridDim.x);
-    uint32_t* my_partial = partial + (size_t)slice * ntiles_all + tile0;
+    uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * ntiles_all + tile0;
     if (EMIT) {
         for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
     } else {
         for (int c = tid; c < (int)gy * stride; c += BIN_THREADS) s_grid[c] = 0;
     }
-    uint32_t r_begin, r_end;
-    slice_rank_range(bucket_work, bucket_ranges, slice, gridDim.x, tid, rw.prefix, r_begin, r_end);   // (barriers inside)
-    const int rounds = (int)((r_end - r_begin + 1023u) >> 10);
+    __syncthreads();
+    const int nwg = (int)gridDim.x;
+    const int rounds = ((P + 63) / 64 + 16 * nwg - 1) / (16 * nwg);
     // The record of the NEXT round is requested before this round's items are walked (a round is a chain of workgroup barriers
     // and LDS searches with one workgroup per CU: nothing else would hide the load).  Unconditional, index clamped: a
     // conditionally assigned load result is waited for on the spot.
-    const uint32_t r_last = min(r_end > r_begin ? r_end - 1u : r_begin, (uint32_t)(P - 1));   // (an empty slice still prefetches once)
-    BlendRec nxt = rank_rec[min(r_begin + (uint32_t)tid, r_last)];
+    BlendRec nxt = rank_rec[min((wave * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
     for (int it = 0; it < rounds; it++) {
-        const uint32_t r = r_begin + ((uint32_t)it << 10) + (uint32_t)tid;   // 1024 consecutive ranks per round
+        const int r = ((it * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
         const BlendRec rec = nxt;
-        nxt = rank_rec[min(r + 1024u, r_last)];
+        nxt = rank_rec[min((((it + 1) * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
         uint32_t h = 0;
-        if (r < r_end) {
+        if (r < P) {
             const int rad = (int)rec.pm;
             if (rad > 0) {
                 uint2 rmin, rmax;
@@ -569,7 +472,6 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
                     s_co[tid] = rec.co;
                     s_grect[tid] = rmin.x | (rmax.x << 10) | (rmin.y << 21);
                     s_grad[tid] = (uint32_t)rad;
-                    if (EMIT) s_gid[tid] = rec.id;
                 }
             }
         }
@@ -579,7 +481,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
         if MI_ABLATE(1 << 20) rows_total = 0;
         for (uint32_t w0 = 0; w0 < rows_total; w0 += 1024) {  // windows of 1024 (Gaussian, tile row) items
             const uint32_t k = w0 + (uint32_t)tid;
-            uint2 smin = make_uint2(0, 0);
+            uint2 smin = make_uint2(0, 0), smax = make_uint2(0, 0);
             uint32_t width = 0;
             if (k < rows_total) {
                 int g = 0;  // first Gaussian slot with prefix > k
@@ -598,8 +500,8 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
                     const int lo = hi0 > lo0 ? (hi1 > lo1 ? min(lo0, lo1) : lo0) : lo1;
                     const int hi = hi0 > lo0 ? (hi1 > lo1 ? max(hi0, hi1) : hi0) : hi1;
                     smin = make_uint2((uint32_t)lo >> 1, ty);
-                    const uint32_t smax_x = ((uint32_t)hi + 1u) >> 1;
-                    width = smax_x - smin.x;
+                    smax = make_uint2(((uint32_t)hi + 1u) >> 1, ty + 1u);
+                    width = smax.x - smin.x;
                     if (EMIT) {
                         s_q0[tid] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | ((uint32_t)g << 22);
                         s_q1[tid] = (uint32_t)lo1 | ((uint32_t)hi1 << 11);
@@ -615,89 +517,30 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
                             atomicAdd(&row[b1], -1);
                         } else {
                             atomicAdd(&row[smin.x], 1);
-                            atomicAdd(&row[smin.x + width], -1);
+                            atomicAdd(&row[smax.x], -1);
                         }
                     }
                 }
             }
             if (EMIT && !MI_ABLATE(1 << 16)) {
-                // ---- second level: the tiles of the window's spans, item i <-> (span, column) in span-major order = in (rank, row,
-                // column) order, STEP_ITEMS at a time; item slot p = 128 wave + 64 j + lane holds item base + p
-                uint32_t total;
-                const uint32_t incl = workgroup_inclusive_scan(width, tid, rw.wsum, total);
-                rw.prefix[tid] = incl;
-                rw.rx[tid] = smin.x | (width << 16);
-                rw.ry[tid] = smin.y;
-                __syncthreads();
-                for (uint32_t base = 0; base < total; base += STEP_ITEMS) {
-#pragma unroll
-                    for (int j = 0; j < STEP_ITEMS / 1024; j++) {
-                        const uint32_t p = 128u * (uint32_t)wave + 64u * (uint32_t)j + (uint32_t)lane;
-                        const uint32_t i = base + p;
-                        uint32_t key = STEP_NOKEY;
-                        if (i < total) {
-                            int o = 0;   // first span with prefix > i
-#pragma unroll
-                            for (int step = 512; step >= 1; step >>= 1)
-                                if (rw.prefix[o + step - 1] <= i) o += step;
-                            const uint32_t tx = (rw.rx[o] & 0xFFFFu) + (i - (o == 0 ? 0u : rw.prefix[o - 1]));
-                            const uint32_t ty = rw.ry[o];
-                            const uint32_t q0 = s_q0[o], q1 = s_q1[o];
-                            const uint32_t lo0 = q0 & 2047u, n0 = ((q0 >> 11) & 2047u) - lo0, lo1 = q1 & 2047u, n1 = ((q1 >> 11) & 2047u) - lo1;
-                            const uint32_t c = 2u * tx;
-                            const uint32_t qmask = (uint32_t)(c - lo0 < n0) | ((uint32_t)(c + 1u - lo0 < n0) << 1) |
-                                                   ((uint32_t)(c - lo1 < n1) << 2) | ((uint32_t)(c + 1u - lo1 < n1) << 3);
-                            if (qmask != 0u) {
-                                key = (ty - by0) * gx + tx;
-                                s_pay[p] = s_gid[q0 >> 22] | (qmask << RANK_BITS);
-                            }
+                for_each_tile_balanced(
+                    rw, tid, smin, smax, width,
+                    [&](uint32_t owner, uint32_t tx, uint32_t ty) {
+                        if MI_ABLATE(1 << 17) return;
+                        const uint32_t q0 = s_q0[owner], q1 = s_q1[owner];
+                        const uint32_t lo0 = q0 & 2047u, n0 = ((q0 >> 11) & 2047u) - lo0, lo1 = q1 & 2047u, n1 = ((q1 >> 11) & 2047u) - lo1;
+                        const uint32_t c = 2u * tx;
+                        const uint32_t qmask = (uint32_t)(c - lo0 < n0) | ((uint32_t)(c + 1u - lo0 < n0) << 1) |
+                                               ((uint32_t)(c - lo1 < n1) << 2) | ((uint32_t)(c + 1u - lo1 < n1) << 3);
+                        if (qmask != 0u) {
+                            const uint32_t slot_g = q0 >> 22;
+                            const uint32_t rank = (uint32_t)(((it * 16 + (int)(slot_g >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(slot_g & 63u));
+                            if MI_ABLATE(1 << 18) return;
+                            const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
+                            if MI_ABLATE(1 << 19) return;
+                            entries[slot] = rank | (qmask << RANK_BITS);
                         }
-                        s_sa[p] = (key << 11) | p;
-                    }
-                    // stable sort of the step's words by tile key: 8 low bits, then the rest (radix_pass: barriers inside, the first
-                    // one behind the stores above)
-                    radix_pass<16, STEP_ITEMS / 1024>(s_sa, s_sb, STEP_ITEMS, 11, s_hist, tid);
-                    radix_pass<16, STEP_ITEMS / 1024>(s_sb, s_sa, STEP_ITEMS, 19, s_hist, tid);
-                    // ---- slots: thread t looks at the sorted words 2 t and 2 t + 1; a run of equal keys starts at the last "head"
-                    // at or in front of a word (max-scan of the head positions over the workgroup), takes its slots in one
-                    // piece from the tile's cursor, and its last word advances the cursor (behind a barrier: no atomics)
-                    const uint32_t w0s = s_sa[2 * tid], w1s = s_sa[2 * tid + 1];
-                    const uint32_t kprev = tid > 0 ? s_sa[2 * tid - 1] >> 11 : 0xFFFFFFFFu;
-                    const uint32_t knext = tid < BIN_THREADS - 1 ? s_sa[2 * tid + 2] >> 11 : 0xFFFFFFFFu;
-                    const uint32_t k0 = w0s >> 11, k1 = w1s >> 11;
-                    const bool head0 = k0 != kprev, head1 = k1 != k0;
-                    // position + 1 of the last head at or in front of word 2 t + 1, 0: none among my two
-                    const uint32_t mine = head1 ? 2u * (uint32_t)tid + 2u : (head0 ? 2u * (uint32_t)tid + 1u : 0u);
-                    uint32_t scan = mine;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const uint32_t t = (uint32_t)__shfl_up((int)scan, o, 64);
-                        if (lane >= o) scan = max(scan, t);
-                    }
-                    if (lane == 63) s_misc[wave] = scan;
-                    __syncthreads();
-                    uint32_t before = 0;   // the same over the waves in front of mine
-#pragma unroll
-                    for (int w = 0; w < 16; w++) before = w < wave ? max(before, s_misc[w]) : before;
-                    const uint32_t up = (uint32_t)__shfl_up((int)scan, 1, 64);
-                    const uint32_t excl = max(before, lane > 0 ? up : 0u);   // over the threads in front of mine
-                    // (word 0 is a head: every word has one at or in front of it)
-                    const uint32_t start0 = head0 ? 2u * (uint32_t)tid : excl - 1u;
-                    const uint32_t start1 = head1 ? 2u * (uint32_t)tid + 1u : start0;
-                    uint32_t slot0 = 0, slot1 = 0;
-                    if (k0 != STEP_NOKEY) slot0 = s_cnt[k0] + (2u * (uint32_t)tid - start0);
-                    if (k1 != STEP_NOKEY) slot1 = s_cnt[k1] + (2u * (uint32_t)tid + 1u - start1);
-                    if (!MI_ABLATE(1 << 19)) {
-                        if (k0 != STEP_NOKEY) blend_list[slot0] = s_pay[w0s & 2047u];
-                        if (k1 != STEP_NOKEY) blend_list[slot1] = s_pay[w1s & 2047u];
-                    }
-                    __syncthreads();   // every cursor of the step has been read
-                    if (k0 != STEP_NOKEY && k1 != k0) s_cnt[k0] = slot0 + 1u;
-                    if (k1 != STEP_NOKEY && knext != k1) s_cnt[k1] = slot1 + 1u;
-                    // (the next step's cursor reads sit behind the barriers of its two radix passes; its s_sa / s_pay stores
-                    // behind this step's reads of them: the barrier above)
-                }
-                __syncthreads();  // the span arrays are rewritten by the next window
+                    });
             }
         }
         __syncthreads();  // the Gaussian arrays are rewritten by the next round

@@ -15,9 +15,6 @@
 //      one wave each (ranking by counting, no barriers); longer ones -- listed by the range scan -- by a workgroup each
 //      (counting up to 512 pairs, LSD radix over the index digits and the s key bits that differ inside a bucket up to
 //      2048 pairs in LDS, ping-ponging in HBM beyond): dense depth layers cost time, not correctness.
-//   5. the same kernels leave bucket_work[bucket] = sum over the bucket's Gaussians of (tiles in the reference rect + 8): the
-//      weights from which the count / emit passes of the lean lists cut the rank axis into contiguous slices of equal work
-//      (binning.h: slice_rank_range) -- a bucket is a contiguous run of ranks, so slice boundaries are bucket boundaries.
 #pragma once
 
 #include "binning.h"
@@ -25,7 +22,6 @@
 namespace mirast {
 
 constexpr int DS_NB = 16384;
-static_assert(DS_NB == SLICE_NB, "binning.h: slice_rank_range walks DS_NB buckets, sixteen per thread");
 constexpr int DS_NBK = DS_NB + 1;  // + the bucket of culled Gaussians
 constexpr int DS_MAX_WG = 128;  // measured 16 / 32 / 64 / 128 / 192 / 256 slices on cfg3: depth order 0.122 / 0.092 / 0.078 / 0.074 / 0.076 / 0.077 ms
 constexpr int DS_WAVE = 256;     // pairs per bucket ranked by ONE wave (four buckets per workgroup, no barriers)
@@ -197,17 +193,6 @@ __device__ __forceinline__ void radix_pass_pairs(Src src, Dst dst, int n, int sh
     __syncthreads();
 }
 
-// Weight of one visible Gaussian in the count / emit passes: the tiles of its reference rect (what the enumeration of its row
-// spans scales with) plus a fixed part (measured against a model of both passes on the synthetic laws: slices of equal
-// sum(tiles + 8) carry 1.04-1.09 x the mean work, slices of equal sum(tiles) 1.9-2.0 x, slices of equal rank counts 2.7-3.3 x).
-constexpr uint32_t SLICE_FIXED_WORK = 8;
-__device__ __forceinline__ uint32_t slice_work_of(const BlendRec& rec, uint32_t gx, uint32_t gy)
-{
-    uint2 rmin, rmax;
-    getRect(rec.xy.x, rec.xy.y, (int)rec.pm, rmin, rmax, gx, gy);
-    return (rmax.x - rmin.x) * (rmax.y - rmin.y) + SLICE_FIXED_WORK;
-}
-
 // Buckets of up to DS_WAVE pairs (the common case: ~100 pairs on a 1 M-Gaussian view): one WAVE per bucket ranks its
 // pairs by counting -- every pair is compared with every other one through LDS broadcast reads; (key, index) pairs
 // are distinct, so the ranks are a permutation -- and scatters sorted_idx / the 32-byte records by rank.
@@ -215,9 +200,7 @@ __global__ void __launch_bounds__(256) depth_bucket_sort_wave_kernel(const uint2
                                                                      const uint2* __restrict__ pairs,
                                                                      const BlendRec* __restrict__ index_rec,
                                                                      uint32_t* __restrict__ sorted_idx,
-                                                                     BlendRec* __restrict__ rank_rec,
-                                                                     uint32_t* __restrict__ bucket_work /* zeroed by the range scan */,
-                                                                     uint32_t gx, uint32_t gy)
+                                                                     BlendRec* __restrict__ rank_rec)
 {
     __shared__ uint32_t s_k[4][DS_WAVE];
     __shared__ uint32_t s_v[4][DS_WAVE];
@@ -249,20 +232,14 @@ __global__ void __launch_bounds__(256) depth_bucket_sort_wave_kernel(const uint2
 #pragma unroll
         for (int t = 0; t < EPL; t++) rank[t] += other < mine[t] ? 1 : 0;
     }
-    uint32_t work = 0;
 #pragma unroll
     for (int t = 0; t < EPL; t++) {
         if (lane + 64 * t < n) {
             const uint32_t g = (uint32_t)mine[t];
-            const BlendRec rec = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
-            rank_rec[range.x + rank[t]] = rec;
+            rank_rec[range.x + rank[t]] = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
             sorted_idx[range.x + rank[t]] = g;
-            work += slice_work_of(rec, gx, gy);
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) work += (uint32_t)__shfl_xor((int)work, o, 64);
-    if (lane == 0) bucket_work[b] = work;
 }
 
 // Sorts the pairs of one bucket by (key, index) and writes sorted_idx / rank_rec for its ranks.
@@ -275,14 +252,12 @@ __global__ void __launch_bounds__(256) depth_bucket_sort_kernel(const uint2* __r
                                                                 int idx_passes, const BlendRec* __restrict__ index_rec,
                                                                 uint32_t* __restrict__ sorted_idx,
                                                                 BlendRec* __restrict__ rank_rec,
-                                                                const int* __restrict__ r_slots,
-                                                                uint32_t* __restrict__ bucket_work, uint32_t gx, uint32_t gy)
+                                                                const int* __restrict__ r_slots)
 {
     __shared__ uint32_t s_k[2][CAP];
     __shared__ uint32_t s_v[2][CAP];
     __shared__ uint32_t s_hist[4][256];
     __shared__ uint32_t s_wsum[4];
-    __shared__ uint32_t s_work[4];
     const int tid = threadIdx.x;
     const int key_passes = (depth_map(r_slots).shift + 7) / 8;  // inside a bucket only the low `shift` key bits differ
     const int nwork = BIG ? (int)big_list[0] : 1;
@@ -291,21 +266,12 @@ __global__ void __launch_bounds__(256) depth_bucket_sort_kernel(const uint2* __r
         const uint2 range = ranges[b];
         const int n = (int)(range.y - range.x);
         if (!BIG && (n == 0 || n > CAP)) return;
-        // (contains a workgroup barrier: called by all threads, once per bucket)
         auto finalize = [&](auto src) {
-            uint32_t work = 0;
             for (int i = tid; i < n; i += 256) {
                 const uint32_t g = src.val(i);
-                const BlendRec rec = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
-                rank_rec[range.x + i] = rec;
+                rank_rec[range.x + i] = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
                 sorted_idx[range.x + i] = g;
-                work += slice_work_of(rec, gx, gy);
             }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) work += (uint32_t)__shfl_xor((int)work, o, 64);
-            if ((tid & 63) == 0) s_work[tid >> 6] = work;
-            __syncthreads();
-            if (tid == 0) bucket_work[b] = s_work[0] + s_work[1] + s_work[2] + s_work[3];
         };
         if (n <= CAP) {
             for (int i = tid; i < n; i += 256) {

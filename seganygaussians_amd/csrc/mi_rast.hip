@@ -87,12 +87,11 @@ struct DepthScratch {
     uint2* ranges;        // [DS_NBK]
     uint32_t* big_list;   // [1 + DS_NB]
     int* out2;            // {V + culled == P, longest bucket}
-    uint32_t* work;       // [DS_NBK] per bucket: sum of (tiles + 8) of its Gaussians (depth_sort.h: slice_work_of)
 };
 size_t depth_sort_temp_bytes(int P, size_t* offs = nullptr)
 {
     const size_t p = P > 0 ? (size_t)P : 1;
-    size_t o[9];
+    size_t o[8];
     size_t at = 256;
     auto take = [&](size_t n) {
         const size_t r = at;
@@ -107,14 +106,13 @@ size_t depth_sort_temp_bytes(int P, size_t* offs = nullptr)
     o[5] = take((size_t)DS_NBK * sizeof(uint2));
     o[6] = take((size_t)(DS_NB + 2) * sizeof(uint32_t));
     o[7] = take(16);
-    o[8] = take((size_t)DS_NBK * sizeof(uint32_t));
     if (offs)
-        for (int i = 0; i < 9; i++) offs[i] = o[i];
+        for (int i = 0; i < 8; i++) offs[i] = o[i];
     return at;
 }
 DepthScratch depth_scratch(char* base, int P)
 {
-    size_t o[9];
+    size_t o[8];
     depth_sort_temp_bytes(P, o);
     DepthScratch d;
     d.cull_counter = (int*)(base + o[0]);
@@ -125,7 +123,6 @@ DepthScratch depth_scratch(char* base, int P)
     d.ranges = (uint2*)(base + o[5]);
     d.big_list = (uint32_t*)(base + o[6]);
     d.out2 = (int*)(base + o[7]);
-    d.work = (uint32_t*)(base + o[8]);
     return d;
 }
 
@@ -418,10 +415,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     // R is known after the preprocess pass; the first kernel of the depth sort stores its partial sums into the host's pinned
     // buffer, and the host reads them while the depth sort and the counting passes run.
     if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host buffer / event");
-    const DepthScratch ds = depth_scratch(geom.sort_temp, P);
     {
         StageTimer t(stream, MI_STAGE_DEPTH_SORT);
         // depth ordering -> sorted_idx[rank] and the per-rank geometry records (depth_sort.h): 6 launches
+        const DepthScratch ds = depth_scratch(geom.sort_temp, P);
         int nwg_d = depth_workgroups(P);
 #ifdef MI_RAST_PROFILING
         if (ablate_env("MI_RAST_NWG_D") > 0) nwg_d = std::min(nwg_d, ablate_env("MI_RAST_NWG_D"));
@@ -434,16 +431,15 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                            (const int*)img.num_rendered, g_host_sync.pinned_dev);
         HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
         hipLaunchKernelGGL(scan_partials_kernel, dim3((DS_NBK + 63) / 64), dim3(1024), 0, stream, DS_NBK, nwg_d, ds.partial, ds.total);
-        // (the range scan also zeroes bucket_work, which the two bucket-sort kernels below fill for the buckets that hold anything)
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), (DS_NBK + 1) * sizeof(uint32_t), stream, DS_NBK, ds.total, ds.ranges, ds.out2,
-                           (uint32_t)DS_WAVE, DS_NB, ds.big_list, (int*)nullptr, ds.work, ds.work);
+                           (uint32_t)DS_WAVE, DS_NB, ds.big_list);
         hipLaunchKernelGGL(depth_bucket_kernel<true>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
                            geom.depth_key, ds.partial, ds.ranges, ds.pairs, geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
         hipLaunchKernelGGL(depth_bucket_sort_wave_kernel, dim3((DS_NB + 3) / 4), dim3(256), 0, stream, ds.ranges, ds.pairs,
-                           geom.index_rec, geom.sorted_idx, geom.rank_rec, ds.work, vp.grid_x, vp.grid_y);
+                           geom.index_rec, geom.sorted_idx, geom.rank_rec);
         hipLaunchKernelGGL((depth_bucket_sort_kernel<DS_WAVE, DS_LARGE, true>), dim3(2048), dim3(256), 0, stream, ds.ranges,
                            ds.big_list, ds.pairs, ds.pairs_tmp, idx_passes, geom.index_rec,
-                           geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered, ds.work, vp.grid_x, vp.grid_y);
+                           geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
     }
     STAGE_CHECK("depth sort");
     // Full lists (the reference's point_list and full-list positions) are materialised on request -- the reference's
@@ -469,7 +465,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                 hipLaunchKernelGGL(bin_spans_kernel<false>, dim3(nwg), dim3(BIN_THREADS),
                                    ((((size_t)(by1 - by0) * count_grid_stride(vp.grid_x) + 3) & ~(size_t)3) + SPAN_LDS_WORDS) * sizeof(uint32_t),
                                    stream, P, geom.rank_rec, img.tile_count, (const uint2*)nullptr, (uint32_t*)nullptr, vp.grid_x,
-                                   vp.grid_y, by0, by1, ds.work, ds.ranges, g_ablate_fwd);
+                                   vp.grid_y, by0, by1, g_ablate_fwd);
         }
         // (one launch for both scans -- every workgroup scans its tiles over the slices, the last one to finish scans the totals
         // behind a device-scope counter and agent-scope fences -- was built and measured in round 4: depth order 0.079 -> 0.086 ms,
@@ -498,7 +494,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     bin = bin_from(bin_base, R);
     const bool verify = !full && (flags & MI_RAST_VERIFY_LISTS) != 0;
     if (R > 0) {
-        if (verify) HIP_TRY(hipMemsetAsync(bin.blend_list, 0, (size_t)R * sizeof(uint32_t), stream));
+        if (verify) HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint32_t), stream));
         {
             StageTimer t(stream, MI_STAGE_EMIT);
             const size_t emit_lds = bin_lds + 8 * 1024 * sizeof(uint32_t);
@@ -511,18 +507,16 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                     hipLaunchKernelGGL(bin_ranks_kernel<false>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
                 else
-                    // (lean lists: every entry goes straight to its final, depth-ordered slot of the blend list -- no per-tile sort)
                     hipLaunchKernelGGL(bin_spans_kernel<true>, dim3(nwg), dim3(BIN_THREADS),
-                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + EMIT_LDS_WORDS) * sizeof(uint32_t), stream, P,
-                                       geom.rank_rec, img.tile_count, img.ranges, bin.blend_list, vp.grid_x, vp.grid_y, by0, by1, ds.work,
-                                       ds.ranges, g_ablate_fwd);
+                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + SPAN_LDS_WORDS) * sizeof(uint32_t), stream, P,
+                                       geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1, g_ablate_fwd);
             }
         }
         STAGE_CHECK("emit ranks");
         if (verify) {   // debugging aid: synchronous
             uint32_t* ctr = reinterpret_cast<uint32_t*>(img.num_rendered + R_SLOTS * R_SLOT_STRIDE + 2);
             HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(uint32_t), stream));
-            hipLaunchKernelGGL(verify_entries_kernel, dim3(ntiles), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges, bin.blend_list, ctr);
+            hipLaunchKernelGGL(verify_entries_kernel, dim3(ntiles), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges, bin.entries, ctr);
             uint32_t unwritten = 0;
             HIP_TRY(hipMemcpyAsync(&unwritten, ctr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
@@ -530,27 +524,28 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                 return fail(MI_RAST_ERR_HIP, "internal error: " + std::to_string(unwritten) + " list slots were counted but not emitted "
                                              "(count / emit passes of bin_spans_kernel disagree)");
         }
+        int rank_bits = 1;
+        while ((1ll << rank_bits) < (long long)P) rank_bits++;
+        int passes = (rank_bits + 7) / 8;
+#ifdef MI_RAST_PROFILING
+        if (g_ablate_fwd & 256) passes = 0;  // timing experiment: skip the radix passes (wrong order)
+#endif
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
-            // Lean lists: nothing to do -- the emit pass stored every entry at its final, depth-ordered position (binning.h).
-            // Full lists (parity tests, `debug`): the emit pass left depth ranks in arrival order; per-tile radix sort, three
-            // list-length classes (256 threads + 20 KB of LDS, 1024 threads + 64 KB, 1024 threads + 112 KB), a class is launched
-            // only if some tile needs it.  The longest list was stored into the host's pinned words right after the range scan,
-            // which finished before the emit pass above even started: this wait does not stall the queue.
-            int rank_bits = 1;
-            while ((1ll << rank_bits) < (long long)P) rank_bits++;
-            const int passes = (rank_bits + 7) / 8;
+            // three list-length classes (256 threads + 20 KB of LDS, 1024 threads + 64 KB, 1024 threads + 112 KB); a class is launched only if
+            // some tile needs it.  The longest list was copied to the host right after the range scan, which
+            // finished before the emit pass above even started: this wait does not stall the queue.
 #define LAUNCH_TILE_SORT(LO, CAP, FB, NT)                                                                                 \
     hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges,  \
                        bin.entries, bin.scratch, geom.sorted_idx, passes, bin.blend_list)
-            if (full) LAUNCH_TILE_SORT(0, 2048, false, 256);
+            LAUNCH_TILE_SORT(0, 2048, false, 256);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
             // lean lists: the counts are the lists' exact lengths (bin_spans_kernel), their sum a lower bound of R
             if (full ? g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R : g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] > R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
-            if (full && max_tile_count > 2048) LAUNCH_TILE_SORT(2048, 6144, false, 1024);
-            if (full && max_tile_count > 6144) LAUNCH_TILE_SORT(6144, 12288, true, 1024);
+            if (max_tile_count > 2048) LAUNCH_TILE_SORT(2048, 6144, false, 1024);
+            if (max_tile_count > 6144) LAUNCH_TILE_SORT(6144, 12288, true, 1024);
 #undef LAUNCH_TILE_SORT
         }
         STAGE_CHECK("tile sort");
