@@ -130,6 +130,11 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override Gaussian count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--rs-ag", action="store_true",
+                    help="N > 1: exchange the feature gradients as reduce-scatter -> rank-local feature update (plain SGD, lr "
+                         "--rs-ag-lr, on this rank's 1/N of the rows) -> all-gather of the updated rows (dist.sharded_update_async) "
+                         "instead of one all-reduce; the next view's blend stage waits for the all-gather only")
+    ap.add_argument("--rs-ag-lr", type=float, default=1e-4)
     ap.add_argument("--dist-single", action="store_true",
                     help="testing only: initialise torch.distributed (RCCL) with a single rank and run the N > 1 step")
     ap.add_argument("--settle", type=float, default=3.0,
@@ -148,6 +153,8 @@ def main():
                     help="A/B aid: 32/64-channel forward on the tile-batched kernel (MI_RAST_TILE_FWD) instead of the wave-per-quadrant one; "
                          "a comparison kernel of the PROFILING build: run with MI_RAST_LIB=seganygaussians_amd/libmi_rast_prof.so "
                          "(python -m seganygaussians_amd.build --profiling)")
+    ap.add_argument("--equal-runs", action="store_true",
+                    help="A/B aid: the backward blend's XCD runs at equal tile counts (MI_RAST_EQUAL_RUNS) instead of work-balanced")
     ap.add_argument("--ref-on-gpu", action="store_true",
                     help="reporting only, after the timed region: also time oracle/_ref (the reference's own kernels, translated "
                          "test-only by oracle/build_ref.py) on the same workload and GPU")
@@ -187,7 +194,7 @@ def main():
                      f"MI_RAST_LIB={_build.PROF_LIB_PATH} python bench.py --tile-fwd ...  (python -m seganygaussians_amd.build --profiling builds it)")
     install_dropin()
     from seganygaussians_amd import rasterizer as R
-    from seganygaussians_amd.dist import allreduce_grads_async
+    from seganygaussians_amd.dist import allreduce_grads_async, sharded_update_async
 
     cfg = scenes.CONFIGS[args.config]
     C, W, H = cfg["C"], cfg["W"], cfg["H"]
@@ -249,9 +256,9 @@ def main():
             print(f"[bench rank {rank}] {time.perf_counter() - t_start:8.3f} s  {msg}", file=sys.stderr, flush=True)
 
     def step():
-        if args.fast_exp or args.tile_fwd or args.exact_exp:
+        if args.fast_exp or args.tile_fwd or args.exact_exp or args.equal_runs:
             with R.forward_flags(fast_exp=True if args.fast_exp else None, tile_fwd=True if args.tile_fwd else None,
-                                 exact_exp=True if args.exact_exp else None):
+                                 exact_exp=True if args.exact_exp else None, equal_runs=True if args.equal_runs else None):
                 return step_()
         return step_()
 
@@ -283,7 +290,13 @@ def main():
         if dist is not None and not state.get("solo"):
             # sum the per-Gaussian feature gradients of the N views over RCCL/xGMI: one flat 128-MB bucket, asynchronous
             # (not in rank 0's reporting-only steps behind the timed regions: a collective only one rank enters never completes)
-            state["pending"] = allreduce_grads_async([feats.grad])
+            if args.rs_ag:
+                # reduce-scatter -> this rank updates its 1/N of the feature rows -> all-gather of the updated rows: the same bytes
+                # on the wire, but only the all-gather (and an optimizer pass over 1/N of the rows) in front of the next blend
+                lr = args.rs_ag_lr
+                state["pending"] = sharded_update_async(feats, feats.grad, lambda prow, grow, lo, hi: prow.add_(grow, alpha=-lr))
+            else:
+                state["pending"] = allreduce_grads_async([feats.grad])
         state.update(radii=radii, color=color.detach(), means2D=means2D)
 
     def barrier():
@@ -607,7 +620,7 @@ def main():
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "sustained": sustained, "timing": timing, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": data,
-            "config": {"workload": what, "parallelism": f"view-sharded x{world}", "counters": counters,
+            "config": {"workload": what, "parallelism": f"view-sharded x{world}" + (" rs-ag" if args.rs_ag and world > 1 else ""), "counters": counters,
                        "lists": "lean (product default: only overlaps that pass the exact-conservative cull are listed; "
                                 "counters E/L from one full-list call)",
                        "arithmetic": "f32 throughout; C=32/64 forward accumulation = exact 3-way bf16 split of f32 operands, "
@@ -623,11 +636,17 @@ def main():
     phase("reporting")
     state["solo"] = False
     if args.dump_grads and not fwd_only:
-        step()
-        barrier()   # waits for this step's all-reduce: feats.grad now holds the sum over the ranks' views
         os.makedirs(args.dump_grads, exist_ok=True)
+        barrier()
+        if args.rs_ag:   # the features this step starts from (updated by every step so far: the same on every rank)
+            np.save(os.path.join(args.dump_grads, f"features_before_rank{rank}.npy"), feats.detach().cpu().numpy())
+        step()
+        barrier()   # waits for this step's exchange: feats.grad holds the sum over the ranks' views (all-reduce) / feats the update (--rs-ag)
         np.save(os.path.join(args.dump_grads, f"camera_{rank}.npy"), np.concatenate([cam.viewmatrix.ravel(), cam.projmatrix.ravel()]))
-        if rank == 0:
+        if args.rs_ag:   # every rank: its LOCAL gradient (the sum only ever exists in shards) and the features after the sharded update
+            np.save(os.path.join(args.dump_grads, f"feature_grad_local_rank{rank}.npy"), feats.grad.detach().cpu().numpy())
+            np.save(os.path.join(args.dump_grads, f"features_rank{rank}.npy"), feats.detach().cpu().numpy())
+        elif rank == 0:
             np.save(os.path.join(args.dump_grads, "feature_grad_rank0.npy"), feats.grad.detach().cpu().numpy())
     if dist is not None:
         dist.destroy_process_group()

@@ -112,7 +112,9 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
                                                            uint32_t big_threshold, int big_limit,
                                                            uint32_t* __restrict__ big_list, int* __restrict__ host_out = nullptr,
-                                                           uint32_t* __restrict__ zero_a = nullptr, uint32_t* __restrict__ zero_b = nullptr)
+                                                           uint32_t* __restrict__ zero_a = nullptr, uint32_t* __restrict__ zero_b = nullptr,
+                                                           uint32_t* __restrict__ run_bounds = nullptr /* [9]: the backward blend's XCD
+                                                               runs (common.h): equal tile counts until the forward blend's walks are known */)
 {
     // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
     // one workgroup scan joins the pieces, and the ranges leave coalesced again.  Items below big_limit with more
@@ -172,6 +174,7 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
         carry += total;
         __syncthreads();   // s_val / s_wave are rewritten by the next segment
     }
+    if (run_bounds != nullptr && tid < 9) run_bounds[tid] = xcd_run_start((uint32_t)tid, (uint32_t)ntiles_all);
     if (tid == 0) {
         num_rendered[0] = (int)carry;       // R (the host already has it from the preprocess pass; kept for checks)
         num_rendered[1] = (int)s_maxcount;  // longest list
@@ -180,6 +183,60 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
             host_out[1] = (int)s_maxcount;
         }
         if (big_list != nullptr) big_list[0] = s_nbig;
+    }
+}
+
+// Run boundaries of the BACKWARD blend from what the forward walked (tile_nsurv: the entries of a tile's list the forward reached
+// before every pixel was opaque -- the tile's cost in both blend kernels; common.h "WORK-balanced runs"), one workgroup, launched
+// behind the forward blend of a view that will be differentiated: scan of (tile_nsurv + XCD_TILE_WEIGHT) over the row-major tile
+// sequence, seven searches for the points of equal weight, the clamp that bounds the backward's grid.  Images above
+// BIN_MAX_TILES_TOTAL tiles keep the equal-count boundaries of the range scan.
+__global__ void __launch_bounds__(1024) run_bounds_from_walks_kernel(int ntiles, const uint32_t* __restrict__ tile_nsurv,
+                                                                      uint32_t* __restrict__ run_bounds)
+{
+    extern __shared__ uint32_t s_w[];   // [ntiles + 1] exclusive prefix of the weights
+    __shared__ uint32_t s_wave2[16];
+    __shared__ uint32_t s_bound2[9];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = (uint32_t)ntiles;
+    for (int i = tid; i < ntiles; i += 1024) s_w[i] = tile_nsurv[i] + XCD_TILE_WEIGHT;
+    __syncthreads();
+    const int per = (ntiles + 1023) / 1024;
+    const int i0 = min(ntiles, tid * per), i1 = min(ntiles, i0 + per);
+    uint32_t sum = 0;
+    for (int i = i0; i < i1; i++) {
+        const uint32_t c = s_w[i];
+        s_w[i] = sum;
+        sum += c;
+    }
+    const uint32_t incl = wave_inclusive_scan(sum, lane);
+    if (lane == 63) s_wave2[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t c = s_wave2[w];
+        woff += w < wave ? c : 0u;
+        total += c;
+    }
+    const uint32_t base = woff + incl - sum;
+    for (int i = i0; i < i1; i++) s_w[i] += base;
+    if (tid == 0) s_w[ntiles] = total;
+    __syncthreads();
+    if (tid >= 1 && tid <= 7) {   // first tile i with 8 W(i) >= k W_total, W(i) = weight in front of tile i
+        const uint64_t want = (uint64_t)tid * (uint64_t)total;
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (8ull * (uint64_t)s_w[mid] >= want) hi = mid;
+            else lo = mid + 1;
+        }
+        s_bound2[tid] = lo;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        xcd_clamp_runs(s_bound2, n);
+        for (int k = 0; k < 9; k++) run_bounds[k] = s_bound2[k];
     }
 }
 

@@ -62,7 +62,8 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     uint32_t* __restrict__ queue_ctr /* eight zeroed work-queue counters (common.h: xcd_grab) */,
     int cstride_arg /* STRIDED: floats between the rows of two Gaussians in `colors` and `dL_dcolors` = the full channel count of
                        the feature this launch handles one channel block of (both pointers then point at the block) */,
-    int cr_arg /* CR == 0: channels of this block that exist in memory */)
+    int cr_arg /* CR == 0: channels of this block that exist in memory */,
+    const uint32_t* __restrict__ run_bounds /* [9]: the XCDs' runs of tiles (common.h: XcdRuns), left in the image buffer by the forward */)
 {
     constexpr int FROW = BwvCfg<C>::FROW, QCAP = BwvCfg<C>::QCAP, FEAT4 = BwvCfg<C>::FEAT4;
     const int cstride = STRIDED ? cstride_arg : CR;   // (a compile-time constant in the common case: no 64-bit multiply, no extra registers)
@@ -519,15 +520,16 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         // is assigned by the workgroup id (id = 8 (4 j + quad) + x: XCD x, j-th tile of its run); the items of the second
         // half are TAKEN from the XCD's queue, and from the other XCDs' queues when that one is empty (xcd_grab): the
         // runs stay contiguous while the XCDs keep pace, and nobody idles when the scene's density does not let them.
-        const uint32_t b = blockIdx.x, nstatic = 32u * xcd_static_len(ntiles);
+        // The runs are work-balanced (common.h): nine boundaries in the image buffer; the grid is sized for the longest run the
+        // clamp allows, ids beyond a run's static part and takers beyond the queued items leave at once.
+        const uint32_t b = blockIdx.x, nstatic = 32u * xcd_static_len_max(ntiles);
         uint32_t item;
         if (b < nstatic) {
             const uint32_t x = b & 7u, jj = b >> 3;
-            const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
-            // (an XCD whose static part is shorter than the longest one leaves its last ids without an item)
+            const uint32_t start = run_bounds[x], len = run_bounds[x + 1u] - start;
             item = (jj >> 2) < len - len / XCD_QUEUE_DIV ? 4u * start + jj : 0xFFFFFFFFu;
         } else {
-            item = xcd_grab(queue_ctr, ntiles, 4u);
+            item = xcd_grab_runs(queue_ctr, xcd_load_runs(run_bounds), 4u);
         }
         if (item != 0xFFFFFFFFu) quadrant(item >> 2, item & 3u);
     }

@@ -24,25 +24,42 @@
 
 namespace mirast {
 
-// workgroup -> (tile, quadrant): every XCD works through a contiguous run of tiles, the four quadrants of a tile on four of its
-// waves at about the same time (common.h; id = 8 (4 j + quad) + x: XCD x, j-th tile of its run).  MI_FWD_MAP = 1 (A/B): tile = id / 4.
-#ifndef MI_FWD_MAP
-#define MI_FWD_MAP 0
-#endif
-__device__ __forceinline__ bool fwd_wave_item(uint32_t b, uint32_t ntiles, uint32_t& tile, uint32_t& quad)
+// workgroup -> (tile, quadrant): every XCD works through contiguous runs of tiles, the four quadrants of a tile on four of its
+// waves at about the same time (common.h; id = 8 (4 j + quad) + x: XCD x, j-th tile of its runs).  The row-major tile sequence is
+// cut into 8 m runs of equal tile counts, run i to XCD i % 8: m = 1 is the one contiguous eighth of the image per XCD of rounds
+// 3-4; with m > 1 every XCD works on m bands spread over the image -- what a tile costs varies over the image of a real scene, and
+// nothing balances the XCDs' TIME but the statistics of what each is handed (a fast XCD cannot take more: the dispatcher deals
+// workgroup b to XCD b % 8 whatever their progress; profiles/r04_xcd_balance.md) -- at the price of more run boundaries, where
+// neighbouring tiles fetch the Gaussians they share into two L2s.
+__host__ __device__ inline uint32_t fwd_runs_longest(uint32_t ntiles, uint32_t m)   // tiles of the XCD that is handed the most
 {
-#if MI_FWD_MAP == 1
-    tile = b >> 2;
-    quad = b & 3u;
-    return tile < ntiles;
-#else
+    uint32_t longest = 0;
+    for (uint32_t x = 0; x < 8u; x++) {
+        uint32_t t = 0;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t i = x + 8u * k;
+            t += (uint32_t)(((uint64_t)(i + 1u) * ntiles) / (8u * m)) - (uint32_t)(((uint64_t)i * ntiles) / (8u * m));
+        }
+        longest = t > longest ? t : longest;
+    }
+    return longest;
+}
+__device__ __forceinline__ bool fwd_wave_item(uint32_t b, uint32_t ntiles, uint32_t m, uint32_t& tile, uint32_t& quad)
+{
     const uint32_t x = b & 7u, jj = b >> 3;
-    const uint32_t start = xcd_run_start(x, ntiles), len = xcd_run_start(x + 1u, ntiles) - start;
-    if ((jj >> 2) >= len) return false;
-    tile = start + (jj >> 2);
+    uint32_t tl = jj >> 2;   // index into the concatenation of XCD x's m runs
     quad = jj & 3u;
-    return true;
-#endif
+    for (uint32_t k = 0; k < m; k++) {
+        const uint32_t i = x + 8u * k;
+        const uint32_t start = (uint32_t)(((uint64_t)i * ntiles) / (8u * m));
+        const uint32_t len = (uint32_t)(((uint64_t)(i + 1u) * ntiles) / (8u * m)) - start;
+        if (tl < len) {
+            tile = start + tl;
+            return true;
+        }
+        tl -= len;
+    }
+    return false;
 }
 
 // Zero-fill riding on the forward blend (include/mi_rast.h: dL_dcolor_next, MI_RAST_PREZERO_BWD).  The backward accumulates
@@ -87,7 +104,8 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed /* zeroed: receives atomicMax */,
     uint32_t* __restrict__ tile_nsurv /* zeroed: receives atomicMax */, const float* __restrict__ bg_color,
-    float* __restrict__ out_color, int cstride_arg /* STRIDED: floats between feature rows (blend_fwd.h) */, FwdZeroFill zfill)
+    float* __restrict__ out_color, int cstride_arg /* STRIDED: floats between feature rows (blend_fwd.h) */, FwdZeroFill zfill,
+    uint32_t runs_per_xcd /* fwd_wave_item's m */)
 {
     static_assert(C == 32 || C == 64, "32-channel accumulator blocks");
     constexpr int F4 = C / 4, NCB = C / 32, XROW = 6 * C, PLANE = 2 * C;  // float4s per row; channel blocks; row / plane bytes
@@ -104,7 +122,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
 
     fwd_zero_fill(zfill, blockIdx.x, gridDim.x, (int)(threadIdx.x & 63));   // (every workgroup, also those without an item)
     uint32_t tile, quad;
-    if (!fwd_wave_item(blockIdx.x, ntiles, tile, quad)) return;
+    if (!fwd_wave_item(blockIdx.x, ntiles, runs_per_xcd, tile, quad)) return;
     const int lane = threadIdx.x & 63;
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
     const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);
@@ -434,7 +452,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     const float* __restrict__ mask, const float* __restrict__ depths, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed, uint32_t* __restrict__ tile_nsurv,
     const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_mask, float* __restrict__ out_depth,
-    FwdZeroFill zfill)
+    FwdZeroFill zfill, uint32_t runs_per_xcd)
 {
     constexpr int C = 3, CE = C + EXTRA, QCAP = 128, FROW = 8;
     __shared__ XRec s_rec[XG];
@@ -445,7 +463,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
 
     fwd_zero_fill(zfill, blockIdx.x, gridDim.x, (int)(threadIdx.x & 63));   // (every workgroup, also those without an item)
     uint32_t tile, quad;
-    if (!fwd_wave_item(blockIdx.x, ntiles, tile, quad)) return;
+    if (!fwd_wave_item(blockIdx.x, ntiles, runs_per_xcd, tile, quad)) return;
     const int lane = threadIdx.x & 63;
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
     const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);

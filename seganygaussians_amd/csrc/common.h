@@ -196,7 +196,7 @@ __device__ __forceinline__ float gauss_exp(float power)
 //                        every item is taken exactly once.  (All of a run queued: 0.597 ms instead of 0.565 -- the counter's
 //                        answer is a round trip in front of every wave's work; persistent waves that request the next item
 //                        ahead of time: 0.63, spills and an uneven tail.)
-__device__ __forceinline__ uint32_t xcd_run_start(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * n) >> 3); }
+__host__ __device__ __forceinline__ uint32_t xcd_run_start(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * n) >> 3); }
 constexpr int XCD_QUEUE_STRIDE = 16;  // uint32 words between the eight queue counters (one 64-byte line each)
 constexpr uint32_t XCD_QUEUE_DIV = 2;  // the queued part of a run is its last 1 / XCD_QUEUE_DIV
 // The queued part of XCD x's run: its last len / XCD_QUEUE_DIV tiles.  xcd_static_len: the longest static part of any run.
@@ -225,6 +225,76 @@ __device__ __forceinline__ uint32_t xcd_grab(uint32_t* __restrict__ counters, ui
     for (uint32_t k = 0; k < 8u; k++) {
         const uint32_t x = (x0 + k) & 7u;
         const uint32_t start = xcd_run_start(x, n), len = xcd_run_start(x + 1u, n) - start;
+        uint32_t got = 0;
+        if (first) got = atomicAdd(&counters[x * XCD_QUEUE_STRIDE], 1u);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (got < (len / XCD_QUEUE_DIV) * per) return (start + len - len / XCD_QUEUE_DIV) * per + got;
+    }
+    return 0xFFFFFFFFu;
+}
+
+// WORK-balanced runs for the backward blend (round 5).  Equal tile counts per XCD are equal TIME only on a scene whose density does
+// not vary over the image: on the second synthetic law (opaque surfaces + floaters; real scenes are of this kind) the slowest XCD
+// ends 20-23 % behind the mean (profiles/r04_xcd_balance.md), and nothing lets a fast XCD take more -- the dispatcher hands
+// workgroup b to XCD b % 8 whatever the XCDs' progress.  What a tile costs the backward is what the forward WALKED of its list
+// (tile_nsurv; the list LENGTH is the wrong weight: an opaque surface ends a long list early), so a one-workgroup scan behind the
+// forward blend (binning.h: run_bounds_from_walks_kernel) cuts the row-major tile sequence into eight contiguous runs of equal
+// sum(tile_nsurv + XCD_TILE_WEIGHT) and leaves the nine boundaries in the image buffer; every forward's range scan writes the
+// equal-count boundaries there first, so the backward always finds valid ones.  A run holds at most XCD_MAX_RUN_FACTOR times the
+// equal share: that bounds the grid the (stateless) backward launches -- ids beyond a run's length exit at once.
+constexpr uint32_t XCD_TILE_WEIGHT = 128;     // a tile's fixed cost (four waves' start-up) in list entries: 32 / 128 / 256 measured, round 4
+constexpr uint32_t XCD_MAX_RUN_FACTOR = 2;
+struct XcdRuns {
+    uint32_t b[9];   // run x = tiles [b[x], b[x + 1])
+};
+__host__ __device__ inline uint32_t xcd_max_run(uint32_t n)
+{
+    const uint32_t m = XCD_MAX_RUN_FACTOR * ((n + 7u) >> 3);
+    return m < n ? m : n;
+}
+__host__ __device__ inline uint32_t xcd_static_len_max(uint32_t n)
+{
+    const uint32_t longest = xcd_max_run(n);
+    return longest - longest / XCD_QUEUE_DIV;
+}
+__host__ __device__ inline uint32_t xcd_queued_tiles_max(uint32_t n) { return n / XCD_QUEUE_DIV; }   // >= sum over the runs of len / DIV
+__device__ __forceinline__ XcdRuns xcd_load_runs(const uint32_t* __restrict__ bounds)
+{
+    XcdRuns r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.b[k] = bounds[k];   // wave-uniform address: scalar loads
+    return r;
+}
+// Clamps eight proposed boundaries (s_bound[1..7], any values) so that every run holds at most xcd_max_run(n) tiles and the runs
+// partition [0, n): one thread.
+__device__ __forceinline__ void xcd_clamp_runs(uint32_t* s_bound, uint32_t n)
+{
+    const uint32_t maxrun = xcd_max_run(n);
+    s_bound[0] = 0u;
+    s_bound[8] = n;
+    for (uint32_t k = 1; k < 8u; k++) {
+        const uint32_t prev = s_bound[k - 1];
+        const uint32_t need = (8u - k) * maxrun;               // what the runs behind boundary k can hold at most
+        const uint32_t lo = max(prev, n > need ? n - need : 0u);
+        const uint32_t hi = min(n, prev + maxrun);
+        s_bound[k] = min(max(s_bound[k], lo), hi);
+    }
+}
+// xcd_grab over given runs: as above; takers beyond the queued items of all eight runs (the grid is sized for the longest runs the
+// clamp allows) find every queue empty after eight probes and get 0xFFFFFFFF.
+__device__ __forceinline__ uint32_t xcd_grab_runs(uint32_t* __restrict__ counters, const XcdRuns& runs, uint32_t per)
+{
+    const uint32_t x0 = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
+    const bool first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;
+    for (uint32_t k = 0; k < 8u; k++) {
+        const uint32_t x = (x0 + k) & 7u;
+        uint32_t start = runs.b[0], end = runs.b[1];
+#pragma unroll
+        for (uint32_t j = 1; j < 8u; j++) {
+            start = x == j ? runs.b[j] : start;
+            end = x == j ? runs.b[j + 1] : end;
+        }
+        const uint32_t len = end - start;
         uint32_t got = 0;
         if (first) got = atomicAdd(&counters[x * XCD_QUEUE_STRIDE], 1u);
         got = __builtin_amdgcn_readfirstlane(got);

@@ -251,6 +251,8 @@ struct ImgPtrs {
     uint32_t* tile_cursor;
     int* num_rendered;
     uint32_t* tile_nsurv;   // per tile: blend-list entries the forward walked
+    uint32_t* run_bounds;   // [9]: the backward blend's XCD runs of tiles (common.h: XcdRuns): equal counts from the range scan,
+                            // work-balanced ones from run_bounds_from_walks_kernel behind the forward blend of a view to be differentiated
 };
 struct BinPtrs {
     uint32_t* entries;   // per overlap: depth rank of the Gaussian, bucketed by tile (unsorted inside a tile)
@@ -292,6 +294,7 @@ ImgPtrs img_from(char* base, int W, int H)
     m.tile_cursor = (uint32_t*)(base + off[MI_IMG_TILE_CURSOR]);
     m.num_rendered = (int*)(base + off[MI_IMG_NUM_RENDERED]);
     m.tile_nsurv = (uint32_t*)(base + off[MI_IMG_TILE_NSURV]);
+    m.run_bounds = reinterpret_cast<uint32_t*>(m.num_rendered + R_SLOTS * R_SLOT_STRIDE + 4);
     return m;
 }
 BinPtrs bin_from(char* base, int R)
@@ -405,6 +408,8 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
+            HIP_TRY(hipFuncSetAttribute((const void*)run_bounds_from_walks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         DS_NBK * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -474,7 +479,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                            img.tile_count, img.tile_cursor);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
                            img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr,
-                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv);
+                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds);
     }
     STAGE_CHECK("tile scan");
     HIP_TRY(hipEventRecord(g_host_sync.ev2, stream));
@@ -600,6 +605,17 @@ void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs
 }
 #endif
 
+// Runs of tiles per XCD in the forward blend (blend_fwd_wave.h: fwd_wave_item).  Profiling build: MI_RAST_FWD_RUNS overrides (A/B).
+constexpr uint32_t FWD_RUNS_PER_XCD = 1;
+inline uint32_t fwd_runs_per_xcd()
+{
+#ifdef MI_RAST_PROFILING
+    const int e = ablate_env("MI_RAST_FWD_RUNS");
+    if (e >= 1 && e <= 16) return (uint32_t)e;
+#endif
+    return FWD_RUNS_PER_XCD;
+}
+
 // One wave per (tile, quadrant): 32 x the longest XCD run of tiles workgroups (blend_fwd_wave.h).
 // xm: common.h ExpMode -- EXP_HYBRID unless the caller's flags say otherwise (exp_mode_of)
 template <int C>
@@ -607,13 +623,14 @@ void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPt
                            const float* features, const float* bg, float* out_color, int xm, int cstride, FwdZeroFill& zfill)
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
-    const uint32_t grid = 32u * ((nt + 7u) >> 3);
+    const uint32_t fm = fwd_runs_per_xcd();
+    const uint32_t grid = 32u * fwd_runs_longest(nt, fm);
     const FwdZeroFill zf = zfill;
     zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};   // taken: the launches of further channel blocks fill nothing
 #define FW_LAUNCH(XM, ST)                                                                                                     \
     hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XM, ST>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_list,           \
                        geom.index_rec, vp.W, vp.H, vp.grid_x, nt, features, img.final_T, img.n_contrib, img.tile_consumed,        \
-                       img.tile_nsurv, bg, out_color, cstride, zf)
+                       img.tile_nsurv, bg, out_color, cstride, zf, fm)
 #define FW_LAUNCH_ST(ST)                                  \
     do {                                                  \
         if (xm == EXP_HYBRID) FW_LAUNCH(EXP_HYBRID, ST);  \
@@ -632,13 +649,14 @@ void launch_blend_fwd_wave_rgb(const ViewParams& vp, hipStream_t stream, const I
                                float* out_depth, int xm, FwdZeroFill& zfill)
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
-    const uint32_t grid = 32u * ((nt + 7u) >> 3);
+    const uint32_t fm = fwd_runs_per_xcd();
+    const uint32_t grid = 32u * fwd_runs_longest(nt, fm);
     const FwdZeroFill zf = zfill;
     zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};
 #define RGB_LAUNCH(XM)                                                                                                                       \
     hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, XM>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_list, geom.index_rec,   \
                        vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,                 \
-                       img.tile_nsurv, bg, out_color, out_mask, out_depth, zf)
+                       img.tile_nsurv, bg, out_color, out_mask, out_depth, zf, fm)
     if (xm == EXP_HYBRID) RGB_LAUNCH(EXP_HYBRID);
     else if (xm == EXP_EXACT) RGB_LAUNCH(EXP_EXACT);
     else RGB_LAUNCH(EXP_FAST);
@@ -930,7 +948,7 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     // tile_count holds partial[slice][tile] of the count / emit passes (binning.h); tile_cursor the tile totals
     off[MI_IMG_TILE_COUNT] = c.take((size_t)BIN_MAX_WG * (tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
-    off[MI_IMG_NUM_RENDERED] = c.take((R_SLOTS * R_SLOT_STRIDE + 4) * sizeof(int));  // R partial sums, then {R, longest list}
+    off[MI_IMG_NUM_RENDERED] = c.take((R_SLOTS * R_SLOT_STRIDE + 16) * sizeof(int));  // R partial sums, then {R, longest list}, then the nine run boundaries
     off[MI_IMG_TILE_NSURV] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     return c.off;
 }
@@ -1088,6 +1106,12 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
         // no wave-per-quadrant launch took the fill (tile-batched / f32 / 16-channel kernels): fill commands
         if (zfill.na) HIP_TRY(hipMemsetAsync(zfill.a, 0, (size_t)zfill.na << 4, stream));
         if (zfill.nb) HIP_TRY(hipMemsetAsync(zfill.b, 0, (size_t)zfill.nb << 4, stream));
+        // A view that will be differentiated (the caller asked for the backward's buffers to be left zeroed): the backward blend's
+        // XCD runs from what this forward walked (common.h "WORK-balanced runs"; inside the forward blend's stage time)
+        const int nt_all = (int)(vp.grid_x * vp.grid_y);
+        if (((flags & MI_RAST_PREZERO_BWD) || dL_dcolor_next != nullptr) && nt_all <= BIN_MAX_TILES_TOTAL && !(flags & MI_RAST_EQUAL_RUNS))
+            hipLaunchKernelGGL(run_bounds_from_walks_kernel, dim3(1), dim3(1024), ((size_t)nt_all + 1) * sizeof(uint32_t), stream, nt_all,
+                               img.tile_nsurv, img.run_bounds);
     }
     STAGE_CHECK("render");
     return MI_RAST_OK;
@@ -1131,9 +1155,9 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         const uint32_t nt_ = vp.grid_x * vp.grid_y;
 #ifdef MI_RAST_PROFILING
 #define LAUNCH_BWD_WAVE_(WPB, XE, ST, ...)                                                                                    \
-    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE, ST>), dim3(WPB == 1 ? 32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_) : nt_), dim3(64 * WPB), 0,    \
+    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE, ST>), dim3(WPB == 1 ? 32u * xcd_static_len_max(nt_) + 4u * xcd_queued_tiles_max(nt_) : nt_), dim3(64 * WPB), 0,    \
                        stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
-                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk, g_ablate)
+                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk, g_ablate, img.run_bounds)
 #define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
     do {                                                                            \
         if (xexp) LAUNCH_BWD_WAVE_(1, true, ST, __VA_ARGS__);                       \
@@ -1142,9 +1166,9 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     } while (0)
 #else
 #define LAUNCH_BWD_WAVE_(XE, ST, ...)                                                                                         \
-    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, XE, ST>), dim3(32u * xcd_static_len(nt_) + 4u * xcd_queued_tiles(nt_)), dim3(64), 0,    \
+    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, XE, ST>), dim3(32u * xcd_static_len_max(nt_) + 4u * xcd_queued_tiles_max(nt_)), dim3(64), 0,    \
                        stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
-                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk)
+                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk, img.run_bounds)
 #define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
     do {                                                                            \
         if (xexp) LAUNCH_BWD_WAVE_(true, ST, __VA_ARGS__);                          \

@@ -14,7 +14,7 @@ small ones.  Passing several tensors coalesces them into a single flat buffer fi
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Sequence
+from typing import Iterable, List, Optional, Sequence  # noqa: F401
 
 import torch
 import torch.distributed as dist
@@ -86,6 +86,90 @@ def allreduce_grads_async(tensors: Sequence[Optional[torch.Tensor]], group=None)
         ev = torch.cuda.Event()
         ev.record(side)
     return ev, (ts, works)
+
+
+def shard_range(numel: int, rank: int, world: int):
+    """Elements [lo, hi) of a flat tensor of `numel` elements that rank `rank` owns: equal shards of ceil(numel / world)
+    elements (the last ones shorter or empty) -- the layout reduce_scatter_tensor / all_gather_into_tensor use on a tensor
+    padded to world * ceil(numel / world)."""
+    per = -(-numel // world)
+    return min(numel, rank * per), min(numel, (rank + 1) * per)
+
+
+def sharded_update_async(param: torch.Tensor, grad: torch.Tensor, update_shard, group=None):
+    """The exchange of a view-sharded step as reduce-scatter -> rank-local update -> all-gather instead of an all-reduce followed
+    by the same update on every rank:
+
+        all-reduce :  every rank receives all P x C summed gradients (2 (N-1)/N S bytes per rank on a ring), then every rank runs
+                      the optimizer over all P rows;
+        this       :  rank r receives the SUM of its 1/N of the rows ((N-1)/N S), runs `update_shard(param_rows, grad_rows, lo, hi)`
+                      on them alone (optimizer state stays sharded: 1/N of Adam's moments per rank) and the UPDATED rows are
+                      gathered ((N-1)/N S).
+
+    The bytes on the wire are the same; what changes is what has to finish before the next view's blend stage: only the all-gather
+    of the updated rows -- the reduce-scatter starts as soon as this view's feature gradients are complete and runs beside the
+    geometry backward, and the optimizer touches 1/N of the rows.  `param` / `grad`: contiguous tensors of the same shape
+    (SAGA: `_point_features` and its .grad, P x C fp32); `update_shard` gets flat views of this rank's elements [lo, hi) of both
+    (grad already summed over the ranks) and updates the parameter view IN PLACE.  On return `param` holds the updated values of
+    every rank's shard once the returned event has fired (CUDA; the call completes everything on CPU tensors and returns
+    (None, None)).  Hand the event to rasterizer.set_features_ready_event like allreduce_grads_async's.  Without an initialised
+    process group the update runs over the whole tensor."""
+    if not (param.is_contiguous() and grad.is_contiguous()) or param.shape != grad.shape:
+        raise ValueError("sharded_update_async needs contiguous param / grad of one shape")
+    n = param.numel()
+    pf, gf = param.detach().view(-1), grad.detach().view(-1)
+    if not (dist.is_available() and dist.is_initialized()):
+        update_shard(pf, gf, 0, n)
+        return None, None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = -(-n // world)
+    lo, hi = shard_range(n, rank, world)
+    native = dist.get_backend(group) == "nccl" or not param.is_cuda   # RCCL, or gloo on host tensors
+
+    def run():
+        if per * world == n:
+            gin, pall = gf, pf
+        else:   # pad to equal shards (never on the benchmark sizes: P x C is a multiple of 8)
+            gin = torch.zeros(per * world, dtype=gf.dtype, device=gf.device)
+            gin[:n].copy_(gf)
+            pall = torch.empty(per * world, dtype=pf.dtype, device=pf.device)
+            pall[:n].copy_(pf)
+        pshard = pall[rank * per:(rank + 1) * per]
+        if native:
+            gshard = torch.empty(per, dtype=gf.dtype, device=gf.device)
+            dist.reduce_scatter_tensor(gshard, gin, op=dist.ReduceOp.SUM, group=group)
+            update_shard(pshard[:hi - lo], gshard[:hi - lo], lo, hi)
+            dist.all_gather_into_tensor(pall, pshard, group=group)   # in place: this rank's shard is where it belongs already
+        else:
+            # gloo on device tensors (the tests' two ranks on one GPU) has neither collective: the same exchange out of the ones
+            # it has -- every rank still updates only its own rows and receives the others' updated rows
+            gsum = gin.clone()
+            dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group)
+            gshard = gsum[rank * per:(rank + 1) * per]
+            update_shard(pshard[:hi - lo], gshard[:hi - lo], lo, hi)
+            parts = [torch.empty_like(pshard) for _ in range(world)]
+            dist.all_gather(parts, pshard.clone(), group=group)
+            for r, part in enumerate(parts):
+                pall[r * per:(r + 1) * per].copy_(part)
+        if pall is not pf:
+            pf.copy_(pall[:n])
+        return gshard, gin, pall
+
+    if not param.is_cuda:
+        run()
+        return None, None
+    dev = param.device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))   # the gradients of this view are complete
+    with torch.cuda.stream(side):
+        keep = run()     # collectives are enqueued behind the side stream's work; neither the host nor the compute stream waits
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for t in (param, grad):
+        t.record_stream(side)
+    return ev, keep
 
 
 class ViewShardedStep:

@@ -110,7 +110,8 @@ _opts = _CallOptions()
 
 
 @contextlib.contextmanager
-def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None, exact_exp=None):
+def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, verify_lists=None, tile_fwd=None, exact_exp=None,
+                  equal_runs=None):
     """Within the block, forwards of this thread run with the given modes: `full_lists` materialises the reference's
     point_list / full-list positions (parity tests), `f32_blend` / `tile_fwd` select the f32 FMA-chain / tile-batched forwards for 32/64
     channels (comparison kernels of the PROFILING build only -- MI_RAST_LIB=libmi_rast_prof.so; the product library refuses them with
@@ -119,12 +120,13 @@ def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, 
     alpha >= 1/255 decisions differ from the reference's); `verify_lists` (debugging aid) checks that the count and emit passes of the
     lean lists agree slot by slot; `exact_exp` makes the forward blend call expf for every pair (product default: the hybrid form of
     csrc/common.h -- same decisions, alpha to 1e-6): alpha / T / n_contrib / final_T are then bit-identical to a build of the
-    reference's kernels.  The flags of a
+    reference's kernels; `equal_runs` (A/B aid) keeps the backward blend's XCD runs at equal tile counts instead of cutting them at
+    equal sums of what the forward walked.  The flags of a
     forward are remembered with its buffers and handed to its backward."""
     prev = _opts.flags
     for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend), (_lib.MI_RAST_NO_CULL, no_cull),
                    (_lib.MI_RAST_FAST_EXP, fast_exp), (_lib.MI_RAST_VERIFY_LISTS, verify_lists),
-                   (_lib.MI_RAST_TILE_FWD, tile_fwd), (_lib.MI_RAST_EXACT_EXP, exact_exp)):
+                   (_lib.MI_RAST_TILE_FWD, tile_fwd), (_lib.MI_RAST_EXACT_EXP, exact_exp), (_lib.MI_RAST_EQUAL_RUNS, equal_runs)):
         if v is not None:
             _opts.flags = (_opts.flags | bit) if v else (_opts.flags & ~bit)
     try:

@@ -11,7 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from seganygaussians_amd import scenes
-from seganygaussians_amd.dist import ViewShardedStep, allreduce_grads, allreduce_grads_async, views_for_rank
+from seganygaussians_amd.dist import (ViewShardedStep, allreduce_grads, allreduce_grads_async, shard_range, sharded_update_async,
+                                      views_for_rank)
 
 NUM_VIEWS, P, W, H, C = 5, 400, 64, 48, 32
 
@@ -67,6 +68,32 @@ def _worker(rank, world, port, out_dir):
         u = torch.full((5,), float(rank + 1))
         ev, keep = allreduce_grads_async([u, None])
         assert ev is None and torch.equal(u, torch.full((5,), float(sum(range(1, world + 1)))))
+        # reduce-scatter -> rank-local update -> all-gather (sharded_update_async) against all-reduce + the same update everywhere:
+        # a momentum step whose state every rank keeps for ITS rows only; odd sizes take the padded path
+        for shape in ((P, C), (7, 3)):
+            g0 = torch.Generator().manual_seed(17)
+            param0 = torch.randn(shape, generator=g0)
+            grads = [torch.randn(shape, generator=g0) for _ in range(world)]    # rank r's local gradient: grads[r] (same on every rank)
+            lo, hi = shard_range(param0.numel(), rank, world)
+            mom = torch.zeros(hi - lo)
+            touched = []
+
+            def update(prow, grow, a, b):
+                assert (a, b) == (lo, hi) and prow.numel() == grow.numel() == b - a
+                touched.append((a, b))
+                mom.mul_(0.9).add_(grow)
+                prow.add_(mom, alpha=-0.1)
+
+            param = param0.clone()
+            for _ in range(2):   # two steps: the sharded momentum carries over
+                ev, keep = sharded_update_async(param, grads[rank].clone(), update)
+                assert ev is None
+            want, m = param0.clone().view(-1), torch.zeros(param0.numel())
+            for _ in range(2):
+                m.mul_(0.9).add_(sum(grads).view(-1))
+                want.add_(m, alpha=-0.1)
+            assert len(touched) == 2 and torch.allclose(param.view(-1), want, rtol=1e-6, atol=1e-6), shape
+            np.save(os.path.join(out_dir, f"sharded_{shape[0]}_{rank}.npy"), param.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -85,6 +112,11 @@ def test_allreduce_is_noop_without_process_group():
     allreduce_grads([t, None])
     assert torch.equal(t, torch.ones(4))
     assert allreduce_grads_async([t]) == (None, None) and torch.equal(t, torch.ones(4))
+    # the sharded update without a process group: one "shard", the whole tensor
+    p, g = torch.ones(3, 2), torch.full((3, 2), 2.0)
+    assert sharded_update_async(p, g, lambda prow, grow, lo, hi: prow.sub_(grow)) == (None, None)
+    assert torch.equal(p, torch.full((3, 2), -1.0))
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)] and shard_range(2, 3, 4) == (2, 2)
 
 
 @pytest.mark.timeout(300)
@@ -100,3 +132,6 @@ def test_view_sharded_step_world2_gloo(tmp_path):
         got_o = np.load(tmp_path / f"opac_grad_{r}.npy")
         np.testing.assert_allclose(got_f, want_f, rtol=1e-5, atol=1e-6 * np.abs(want_f).max())
         np.testing.assert_allclose(got_o.reshape(-1), want_o.reshape(-1), rtol=1e-5, atol=1e-6 * np.abs(want_o).max())
+    # the sharded update left every rank with the same, fully updated parameter
+    for n in (P, 7):
+        np.testing.assert_array_equal(np.load(tmp_path / f"sharded_{n}_0.npy"), np.load(tmp_path / f"sharded_{n}_1.npy"))

@@ -315,13 +315,17 @@ def test_three_steps_on_single_rank_rccl_group():
     assert max(r["image_rel"]) < 1e-6 and max(r["dopacity_rel"]) < 1e-4, r
 
 
-def test_bench_two_ranks_share_the_one_gpu(tmp_path):
+@pytest.mark.parametrize("exchange", ["allreduce", "rs-ag"])
+def test_bench_two_ranks_share_the_one_gpu(tmp_path, exchange):
     """The N > 1 code path of bench.py itself with a REAL second rank on the hardware that is there: `python -m
     torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with both ranks on cuda:0 and a gloo group (MI_BENCH_SHARE_GPU /
     MI_BENCH_DIST_BACKEND: RCCL refuses two ranks on one device) -- the settle-flag all-reduce, the per-block MAX over ranks,
-    allreduce_grads_async + the features-ready event handed to the next forward, every rank rendering its own camera, the
-    sustained region's agreed step count.  Checked: one JSON line from rank 0 with n_gpus 2, and the feature gradient rank 0 holds
-    after a step == the SUM of the two cameras' single-rank gradients."""
+    the asynchronous exchange + the features-ready event handed to the next forward, every rank rendering its own camera, the
+    sustained region's agreed step count.  Checked: one JSON line from rank 0 with n_gpus 2, and
+      allreduce : the feature gradient rank 0 holds after a step == the SUM of the two cameras' single-rank gradients (SURVEY.md 8(e));
+      rs-ag     : (--rs-ag: reduce-scatter -> rank-local SGD update of 1/N of the rows -> all-gather, dist.sharded_update_async) both ranks
+                  hold the same features before and after the step, after == before - lr * (sum of the two local gradients), and each
+                  local gradient is the single-rank gradient of that rank's camera at the features the step started from."""
     import json
     import socket
     import subprocess
@@ -330,12 +334,14 @@ def test_bench_two_ranks_share_the_one_gpu(tmp_path):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    Pn = 30_000
+    Pn, lr = 30_000, 50.0
     env = dict(os.environ, MI_BENCH_SHARE_GPU="1", MI_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MI_BENCH_TRACE="1",
                GLOO_SOCKET_IFNAME="lo")   # (the box's hostname need not resolve)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--points", str(Pn),
            "--settle", "0.2", "--dist-blocks", "2", "--sustained-seconds", "0.05", "--no-cpu-baseline", "--dump-grads", str(tmp_path)]
+    if exchange == "rs-ag":
+        cmd += ["--rs-ag", "--rs-ag-lr", str(lr)]   # (a step large enough to see: gradients are ~1e-6)
     import signal
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root, env=env, start_new_session=True)
     try:
@@ -358,7 +364,7 @@ def test_bench_two_ranks_share_the_one_gpu(tmp_path):
     line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0 and line["scaling"] == "weak"
     assert "x2" in line["config"]["parallelism"] and line["sustained"]["steps"] >= 4
-    got = np.load(tmp_path / "feature_grad_rank0.npy").astype(np.float64)
+    assert ("rs-ag" in line["config"]["parallelism"]) == (exchange == "rs-ag")
     # the same two views, one after the other, on this process: bench.py's scene, cameras (rank 0 front, rank 1 orbit) and dL
     c = scenes.CONFIGS["cfg3"]
     sc = scenes.scene_of_config("cfg3", seed=0, P=Pn)
@@ -367,12 +373,20 @@ def test_bench_two_ranks_share_the_one_gpu(tmp_path):
     _, _, Rz = R.make_rasterizer(c["C"])
     from diff_gaussian_rasterization_contrastive_f import GaussianRasterizationSettings
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).cuda()
-    want = np.zeros_like(got)
+    if exchange == "rs-ag":
+        before = [np.load(tmp_path / f"features_before_rank{r}.npy") for r in range(2)]
+        after = [np.load(tmp_path / f"features_rank{r}.npy") for r in range(2)]
+        np.testing.assert_array_equal(before[0], before[1], err_msg="features before the step differ between the ranks")
+        np.testing.assert_array_equal(after[0], after[1], err_msg="features after the sharded update differ between the ranks")
+        start = before[0]
+    else:
+        start = sc.features
+    single = []
     for rank in range(2):
         cam = scenes.look_at_camera(c["W"], c["H"], c["focal"]) if rank == 0 else scenes.orbit_camera(c["W"], c["H"], c["focal"], 0.05, 0.02)
         dumped = np.load(tmp_path / f"camera_{rank}.npy")
         np.testing.assert_array_equal(dumped, np.concatenate([cam.viewmatrix.ravel(), cam.projmatrix.ravel()]))
-        feats = t(sc.features).requires_grad_(True)
+        feats = t(start).requires_grad_(True)
         st = GaussianRasterizationSettings(image_height=c["H"], image_width=c["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
                                            bg=torch.zeros(c["C"]).cuda(), scale_modifier=1.0, viewmatrix=t(cam.viewmatrix),
                                            projmatrix=t(cam.projmatrix), sh_degree=0, campos=t(cam.campos), prefiltered=False, debug=False)
@@ -380,9 +394,20 @@ def test_bench_two_ranks_share_the_one_gpu(tmp_path):
         color, _ = Rz(st)(means3D=m3, means2D=torch.zeros_like(m3), shs=None, colors_precomp=feats, opacities=t(sc.opacities),
                           scales=t(sc.scales), rotations=t(sc.rotations), cov3D_precomp=None)
         torch.autograd.backward(color, grad_tensors=dL)
-        want += feats.grad.detach().cpu().numpy().astype(np.float64)
+        single.append(feats.grad.detach().cpu().numpy().astype(np.float64))
+    want = single[0] + single[1]
     assert np.abs(want).max() > 0
-    hp.assert_close("all-reduced feature gradient of two ranks", got, want, rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
+    if exchange == "rs-ag":
+        local = [np.load(tmp_path / f"feature_grad_local_rank{r}.npy").astype(np.float64) for r in range(2)]
+        for r in range(2):
+            hp.assert_close(f"local feature gradient of rank {r}", local[r], single[r], rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
+        moved = after[0].astype(np.float64) - start.astype(np.float64)
+        assert np.abs(moved).max() > 0
+        # the update is exactly -lr * (sum of the dumped local gradients), up to float32 rounding of the two operations
+        np.testing.assert_allclose(moved, -lr * (local[0] + local[1]), rtol=1e-4, atol=2e-6 * np.abs(start).max())
+    else:
+        got = np.load(tmp_path / "feature_grad_rank0.npy").astype(np.float64)
+        hp.assert_close("all-reduced feature gradient of two ranks", got, want, rtol=2e-4, flip_frac=hp.GRAD_FLIP_FRAC)
 
 
 def test_bench_on_a_ply_scene_with_colmap_cameras(tmp_path):
