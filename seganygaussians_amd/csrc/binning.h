@@ -107,22 +107,32 @@ constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_TILES = 26 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 57 KB of hand-off
                                                // arrays must fit in 160 KB; larger images are walked in bands of tile rows
 constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
+constexpr int RUN_MODEL_MAX_TILES = 20 * 1024 - 64;  // ... and, up to this many tiles, the modelled work of the XCD runs beside them
 
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
                                                            uint32_t big_threshold, int big_limit,
                                                            uint32_t* __restrict__ big_list, int* __restrict__ host_out = nullptr,
                                                            uint32_t* __restrict__ zero_a = nullptr, uint32_t* __restrict__ zero_b = nullptr,
-                                                           uint32_t* __restrict__ run_bounds = nullptr /* [9]: the backward blend's XCD
-                                                               runs (common.h): equal tile counts until the forward blend's walks are known */)
+                                                           uint32_t* __restrict__ run_bounds = nullptr /* [9]: the blend kernels' XCD runs
+                                                               (common.h): equal tile counts, or equal MODELLED work when run_cap > 0 */,
+                                                           uint32_t run_cap = 0, uint32_t run_fix = 0)
 {
     // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
     // one workgroup scan joins the pieces, and the ranges leave coalesced again.  Items below big_limit with more
     // than big_threshold entries are appended to big_list (count in big_list[0], order arbitrary).
     // More than BIN_MAX_TILES_TOTAL items (images beyond 10 Mpx) are walked in segments of that many, one after the other, the
     // running total carried along: ONE pass of the loop below for every image up to 4096 x 2544.
-    extern __shared__ uint32_t s_val[];  // [min(ntiles_all, BIN_MAX_TILES_TOTAL) + 1]
+    // run_cap > 0 (images up to RUN_MODEL_MAX_TILES tiles: one segment): the XCD runs of the blend kernels are cut at equal sums of the
+    // MODELLED cost of a tile, min(list length, run_cap) + run_fix -- a list is walked until its pixels are opaque, which takes about
+    // run_cap entries where the scene is dense, and to its end where it is sparse; what a walk really covers is only known behind the
+    // forward blend (run_bounds_from_walks_kernel) -- the second prefix sum rides on the first.
+    extern __shared__ uint32_t s_val[];  // [min(ntiles_all, BIN_MAX_TILES_TOTAL) + 1] (+ the same again for the weights when run_cap > 0)
     __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_wave_w[16];
+    __shared__ uint32_t s_bound[9];
+    const bool weighted = run_bounds != nullptr && run_cap > 0u && ntiles_all <= RUN_MODEL_MAX_TILES;
+    uint32_t* const s_w = s_val + (ntiles_all + 1);
     __shared__ uint32_t s_maxcount;
     __shared__ uint32_t s_nbig;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -137,15 +147,23 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
         __syncthreads();
         const int per = (ntiles + 1023) / 1024;
         const int i0 = min(ntiles, tid * per), i1 = min(ntiles, i0 + per);
-        uint32_t sum = 0, mx = 0;
+        uint32_t sum = 0, mx = 0, wsum = 0;
         for (int i = i0; i < i1; i++) {
             const uint32_t c = s_val[i];
             s_val[i] = sum;  // exclusive prefix inside the piece
             sum += c;
             mx = max(mx, c);
+            if (weighted) {
+                s_w[i] = wsum;
+                wsum += min(c, run_cap) + run_fix;
+            }
         }
         const uint32_t incl = wave_inclusive_scan(sum, lane);
-        if (lane == 63) s_wave[wave] = incl;
+        const uint32_t incl_w = weighted ? wave_inclusive_scan(wsum, lane) : 0u;
+        if (lane == 63) {
+            s_wave[wave] = incl;
+            s_wave_w[wave] = incl_w;
+        }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
         __syncthreads();
@@ -160,6 +178,18 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
         const uint32_t piece_base = carry + woff + incl - sum;
         for (int i = i0; i < i1; i++) s_val[i] += piece_base;
         if (tid == 0) s_val[ntiles] = carry + total;
+        if (weighted) {
+            uint32_t woff_w = 0, total_w = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                const uint32_t c = s_wave_w[w];
+                woff_w += w < wave ? c : 0u;
+                total_w += c;
+            }
+            const uint32_t base_w = woff_w + incl_w - wsum;
+            for (int i = i0; i < i1; i++) s_w[i] += base_w;
+            if (tid == 0) s_w[ntiles] = total_w;
+        }
         __syncthreads();
         for (int i = tid; i < ntiles; i += 1024) {
             const uint32_t lo = s_val[i], hi = s_val[i + 1];
@@ -174,7 +204,31 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
         carry += total;
         __syncthreads();   // s_val / s_wave are rewritten by the next segment
     }
-    if (run_bounds != nullptr && tid < 9) run_bounds[tid] = xcd_run_start((uint32_t)tid, (uint32_t)ntiles_all);
+    if (run_bounds != nullptr) {
+        const uint32_t n = (uint32_t)ntiles_all;
+        if (tid >= 1 && tid <= 7) {
+            uint32_t bk = xcd_run_start((uint32_t)tid, n);
+            if (weighted) {   // first tile i with 8 W(i) >= k W_total, W(i) = modelled work in front of tile i (s_w: still this segment's)
+                const uint64_t want = (uint64_t)tid * (uint64_t)s_w[n];
+                uint32_t lo = 0, hi = n;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (8ull * (uint64_t)s_w[mid] >= want) hi = mid;
+                    else lo = mid + 1;
+                }
+                bk = lo;
+            }
+            s_bound[tid] = bk;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            xcd_clamp_runs(s_bound, n);
+            for (int k = 0; k < 9; k++) {
+                run_bounds[k] = s_bound[k];
+                if (host_out != nullptr) host_out[4 + k] = (int)s_bound[k];   // the forward's grid is sized for its longest run
+            }
+        }
+    }
     if (tid == 0) {
         num_rendered[0] = (int)carry;       // R (the host already has it from the preprocess pass; kept for checks)
         num_rendered[1] = (int)s_maxcount;  // longest list

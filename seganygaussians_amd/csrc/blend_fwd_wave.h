@@ -44,11 +44,19 @@ __host__ __device__ inline uint32_t fwd_runs_longest(uint32_t ntiles, uint32_t m
     }
     return longest;
 }
-__device__ __forceinline__ bool fwd_wave_item(uint32_t b, uint32_t ntiles, uint32_t m, uint32_t& tile, uint32_t& quad)
+// m == 0: ONE run per XCD with the boundaries the range scan left in the image buffer (binning.h: tile_ranges_kernel, equal MODELLED
+// work); the grid is sized for the longest run.
+__device__ __forceinline__ bool fwd_wave_item(uint32_t b, uint32_t ntiles, uint32_t m, const uint32_t* __restrict__ run_bounds,
+                                              uint32_t& tile, uint32_t& quad)
 {
     const uint32_t x = b & 7u, jj = b >> 3;
     uint32_t tl = jj >> 2;   // index into the concatenation of XCD x's m runs
     quad = jj & 3u;
+    if (m == 0u) {
+        const uint32_t start = run_bounds[x], len = run_bounds[x + 1u] - start;
+        tile = start + tl;
+        return tl < len;
+    }
     for (uint32_t k = 0; k < m; k++) {
         const uint32_t i = x + 8u * k;
         const uint32_t start = (uint32_t)(((uint64_t)i * ntiles) / (8u * m));
@@ -98,16 +106,22 @@ __device__ __forceinline__ void fwd_zero_fill(const FwdZeroFill& z, uint32_t wg,
 #endif
 
 // XM: how opacity * exp(power) is evaluated (common.h: ExpMode) -- EXP_HYBRID is the product default.
-template <int C, int XM = EXP_HYBRID, bool STRIDED = false>
+// PARTIAL: only the first `cr_arg` (1 .. 31) of the block's 32 channels exist in memory -- the last channel block of a feature whose
+// width is no multiple of 32 (the reference compiles ANY NUM_CHANNELS, config_contrastive_f.h:15): feature rows are loaded channel by
+// channel with zeros behind cr (zeros in the MFMA operands, as RGB has always been blended), and only cr planes are written.
+template <int C, int XM = EXP_HYBRID, bool STRIDED = false, bool PARTIAL = false>
 __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64) blend_fwd_wave_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed /* zeroed: receives atomicMax */,
     uint32_t* __restrict__ tile_nsurv /* zeroed: receives atomicMax */, const float* __restrict__ bg_color,
     float* __restrict__ out_color, int cstride_arg /* STRIDED: floats between feature rows (blend_fwd.h) */, FwdZeroFill zfill,
-    uint32_t runs_per_xcd /* fwd_wave_item's m */)
+    uint32_t runs_per_xcd /* fwd_wave_item's m */, const uint32_t* __restrict__ run_bounds /* [9], m == 0 */,
+    int cr_arg /* PARTIAL: channels of this block that exist (1 .. 31) */)
 {
     static_assert(C == 32 || C == 64, "32-channel accumulator blocks");
+    static_assert(!PARTIAL || (C == 32 && STRIDED), "a partial block is the 32-channel remainder of a wider (or narrower) feature");
+    const int cr = PARTIAL ? cr_arg : C;
     constexpr int F4 = C / 4, NCB = C / 32, XROW = 6 * C, PLANE = 2 * C;  // float4s per row; channel blocks; row / plane bytes
     constexpr int QCAP = 128;
     constexpr int NK = XG * F4 / 64;   // float4 feature parts per lane and group
@@ -122,7 +136,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
 
     fwd_zero_fill(zfill, blockIdx.x, gridDim.x, (int)(threadIdx.x & 63));   // (every workgroup, also those without an item)
     uint32_t tile, quad;
-    if (!fwd_wave_item(blockIdx.x, ntiles, runs_per_xcd, tile, quad)) return;
+    if (!fwd_wave_item(blockIdx.x, ntiles, runs_per_xcd, run_bounds, tile, quad)) return;
     const int lane = threadIdx.x & 63;
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
     const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);
@@ -188,7 +202,13 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
             const int e = lane + 64 * k;
             const int g = min(e / F4, n - 1), part = e % F4;
             const size_t gid = (size_t)(s_queue[(qh + ahead + g) & (QCAP - 1)].y & RANK_MASK);
-            rr.f[k] = reinterpret_cast<const float4*>(features + gid * (size_t)cstride)[part];
+            if constexpr (PARTIAL) {   // channel by channel, zeros behind cr (never reads past the row)
+                const float* row = features + gid * (size_t)cstride + 4 * part;
+                rr.f[k] = make_float4(4 * part + 0 < cr ? row[0] : 0.f, 4 * part + 1 < cr ? row[1] : 0.f,
+                                      4 * part + 2 < cr ? row[2] : 0.f, 4 * part + 3 < cr ? row[3] : 0.f);
+            } else {
+                rr.f[k] = reinterpret_cast<const float4*>(features + gid * (size_t)cstride)[part];
+            }
         }
     };
 
@@ -430,7 +450,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
                     const int ch = 32 * cb + 8 * part + c;
-                    out_color[ch * HW + pix_id] = tp[c * 65 + lane] + T * bg_color[ch];
+                    if (!PARTIAL || ch < cr) out_color[ch * HW + pix_id] = tp[c * 65 + lane] + T * bg_color[ch];
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -452,7 +472,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     const float* __restrict__ mask, const float* __restrict__ depths, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed, uint32_t* __restrict__ tile_nsurv,
     const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_mask, float* __restrict__ out_depth,
-    FwdZeroFill zfill, uint32_t runs_per_xcd)
+    FwdZeroFill zfill, uint32_t runs_per_xcd, const uint32_t* __restrict__ run_bounds)
 {
     constexpr int C = 3, CE = C + EXTRA, QCAP = 128, FROW = 8;
     __shared__ XRec s_rec[XG];
@@ -463,7 +483,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
 
     fwd_zero_fill(zfill, blockIdx.x, gridDim.x, (int)(threadIdx.x & 63));   // (every workgroup, also those without an item)
     uint32_t tile, quad;
-    if (!fwd_wave_item(blockIdx.x, ntiles, runs_per_xcd, tile, quad)) return;
+    if (!fwd_wave_item(blockIdx.x, ntiles, runs_per_xcd, run_bounds, tile, quad)) return;
     const int lane = threadIdx.x & 63;
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
     const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);

@@ -137,7 +137,7 @@ struct HostSync {
     bool init()
     {
         if (ok) return true;
-        if (hipHostMalloc((void**)&pinned, (R_SLOTS * R_SLOT_STRIDE + 4) * sizeof(int), hipHostMallocMapped) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&pinned, (R_SLOTS * R_SLOT_STRIDE + 16) * sizeof(int), hipHostMallocMapped) != hipSuccess) return false;
         if (hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess) return false;
@@ -251,8 +251,9 @@ struct ImgPtrs {
     uint32_t* tile_cursor;
     int* num_rendered;
     uint32_t* tile_nsurv;   // per tile: blend-list entries the forward walked
-    uint32_t* run_bounds;   // [9]: the backward blend's XCD runs of tiles (common.h: XcdRuns): equal counts from the range scan,
-                            // work-balanced ones from run_bounds_from_walks_kernel behind the forward blend of a view to be differentiated
+    uint32_t* run_bounds;   // [9]: the blend kernels' XCD runs of tiles (common.h: XcdRuns): from the range scan (equal counts, or equal
+                            // modelled work), replaced by run_bounds_from_walks_kernel behind the forward blend when that is switched on
+    uint32_t longest_run;   // host copy of the longest of those runs (forward only: read from the pinned words at the ev2 wait)
 };
 struct BinPtrs {
     uint32_t* entries;   // per overlap: depth rank of the Gaussian, bucketed by tile (unsorted inside a tile)
@@ -295,6 +296,7 @@ ImgPtrs img_from(char* base, int W, int H)
     m.num_rendered = (int*)(base + off[MI_IMG_NUM_RENDERED]);
     m.tile_nsurv = (uint32_t*)(base + off[MI_IMG_TILE_NSURV]);
     m.run_bounds = reinterpret_cast<uint32_t*>(m.num_rendered + R_SLOTS * R_SLOT_STRIDE + 4);
+    m.longest_run = 0;
     return m;
 }
 BinPtrs bin_from(char* base, int R)
@@ -343,6 +345,33 @@ inline size_t bwd_pack_bytes(int P)
 bool channels_supported(int c) { return c >= 1 && c <= MAX_CHANNELS; }
 // next block of a feature with `rem` channels left (rem < 16: a 16-channel block of which `rem` exist)
 int channel_block(int rem) { return rem >= 64 ? 64 : (rem >= 32 ? 32 : 16); }
+
+// How the blend kernels' tiles are dealt to the eight XCDs (common.h, blend_fwd_wave.h: fwd_wave_item, binning.h: tile_ranges_kernel).
+// Product constants; the profiling build reads overrides from the environment for A/B runs (MI_RAST_FWD_RUNS, MI_RAST_RUN_CAP,
+// MI_RAST_RUN_FIX, MI_RAST_BWD_SCAN).
+constexpr int FWD_RUNS_PER_XCD = 1;   // forward: m interleaved runs of equal tile counts per XCD; 0: one run per XCD, boundaries from the range scan
+constexpr int RUN_MODEL_CAP = 0;      // range scan: XCD runs of equal sum(min(list length, cap) + fix); 0: equal tile counts
+constexpr int RUN_MODEL_FIX = 64;
+constexpr int BWD_RUNS_FROM_WALKS = 1;   // forward of a view to be differentiated: the backward's runs from what it walked (one more small launch)
+inline int knob(const char* name, int dflt)
+{
+#ifdef MI_RAST_PROFILING
+    const char* e = getenv(name);
+    if (e) return atoi(e);
+#endif
+    (void)name;
+    return dflt;
+}
+inline uint32_t fwd_runs_per_xcd() { return (uint32_t)std::min(16, std::max(0, knob("MI_RAST_FWD_RUNS", FWD_RUNS_PER_XCD))); }
+inline uint32_t longest_of(const int* bounds, uint32_t ntiles)
+{
+    uint32_t longest = 0;
+    for (int x = 0; x < 8; x++) {
+        const uint32_t a = (uint32_t)bounds[x], b = (uint32_t)bounds[x + 1];
+        longest = std::max(longest, b >= a ? b - a : 0u);
+    }
+    return std::min(std::max(longest, (ntiles + 7u) >> 3), xcd_max_run(ntiles));
+}
 
 // Stages shared by forward and mask_forward: CF/cuda_rasterizer/rasterizer_impl.cu:246-317.
 int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_rast_resize_fn binning_buffer,
@@ -477,9 +506,12 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         // tile scan 0.058 -> 0.060 ms on cfg3; the fences and the serial tail inside the kernel cost more than the launch they save)
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor, img.ranges,
-                           img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr,
-                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds);
+        const uint32_t run_cap = ntiles <= RUN_MODEL_MAX_TILES ? (uint32_t)std::max(0, knob("MI_RAST_RUN_CAP", RUN_MODEL_CAP)) : 0u;
+        const uint32_t run_fix = (uint32_t)std::max(0, knob("MI_RAST_RUN_FIX", RUN_MODEL_FIX));
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024),
+                           ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * (run_cap ? 2 : 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor,
+                           img.ranges, img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr,
+                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds, run_cap, run_fix);
     }
     STAGE_CHECK("tile scan");
     HIP_TRY(hipEventRecord(g_host_sync.ev2, stream));
@@ -545,6 +577,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                        bin.entries, bin.scratch, geom.sorted_idx, passes, bin.blend_list)
             LAUNCH_TILE_SORT(0, 2048, false, 256);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
+            img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + 4, (uint32_t)ntiles);
             // lean lists: the counts are the lists' exact lengths (bin_spans_kernel), their sum a lower bound of R
             if (full ? g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R : g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] > R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
@@ -558,6 +591,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         // no overlap at all (every tile's range is {0, 0}: the blend kernels read no list).  The range scan stores {total, longest list} into this thread's pinned words: never return while that store can still
         // land (the next forward of this thread, on another stream, would read them)
         HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
+        img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + 4, (uint32_t)ntiles);
     }
     return MI_RAST_OK;
 }
@@ -605,40 +639,35 @@ void launch_blend_fwd_x3(const ViewParams& vp, hipStream_t stream, const ImgPtrs
 }
 #endif
 
-// Runs of tiles per XCD in the forward blend (blend_fwd_wave.h: fwd_wave_item).  Profiling build: MI_RAST_FWD_RUNS overrides (A/B).
-constexpr uint32_t FWD_RUNS_PER_XCD = 1;
-inline uint32_t fwd_runs_per_xcd()
-{
-#ifdef MI_RAST_PROFILING
-    const int e = ablate_env("MI_RAST_FWD_RUNS");
-    if (e >= 1 && e <= 16) return (uint32_t)e;
-#endif
-    return FWD_RUNS_PER_XCD;
-}
-
 // One wave per (tile, quadrant): 32 x the longest XCD run of tiles workgroups (blend_fwd_wave.h).
 // xm: common.h ExpMode -- EXP_HYBRID unless the caller's flags say otherwise (exp_mode_of)
 template <int C>
 void launch_blend_fwd_wave(const ViewParams& vp, hipStream_t stream, const ImgPtrs& img, const BinPtrs& bin, const GeomPtrs& geom,
-                           const float* features, const float* bg, float* out_color, int xm, int cstride, FwdZeroFill& zfill)
+                           const float* features, const float* bg, float* out_color, int xm, int cstride, FwdZeroFill& zfill, int cr = C)
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
     const uint32_t fm = fwd_runs_per_xcd();
-    const uint32_t grid = 32u * fwd_runs_longest(nt, fm);
+    const uint32_t grid = 32u * (fm ? fwd_runs_longest(nt, fm) : (img.longest_run ? img.longest_run : xcd_max_run(nt)));
     const FwdZeroFill zf = zfill;
     zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};   // taken: the launches of further channel blocks fill nothing
-#define FW_LAUNCH(XM, ST)                                                                                                     \
-    hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XM, ST>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_list,           \
+#define FW_LAUNCH(XM, ST, PT)                                                                                                 \
+    hipLaunchKernelGGL((blend_fwd_wave_kernel<C, XM, ST, PT>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_list,       \
                        geom.index_rec, vp.W, vp.H, vp.grid_x, nt, features, img.final_T, img.n_contrib, img.tile_consumed,        \
-                       img.tile_nsurv, bg, out_color, cstride, zf, fm)
-#define FW_LAUNCH_ST(ST)                                  \
-    do {                                                  \
-        if (xm == EXP_HYBRID) FW_LAUNCH(EXP_HYBRID, ST);  \
-        else if (xm == EXP_EXACT) FW_LAUNCH(EXP_EXACT, ST); \
-        else FW_LAUNCH(EXP_FAST, ST);                     \
+                       img.tile_nsurv, bg, out_color, cstride, zf, fm, img.run_bounds, cr)
+#define FW_LAUNCH_ST(ST, PT)                                  \
+    do {                                                      \
+        if (xm == EXP_HYBRID) FW_LAUNCH(EXP_HYBRID, ST, PT);  \
+        else if (xm == EXP_EXACT) FW_LAUNCH(EXP_EXACT, ST, PT); \
+        else FW_LAUNCH(EXP_FAST, ST, PT);                     \
     } while (0)
-    if (cstride == C) FW_LAUNCH_ST(false);
-    else FW_LAUNCH_ST(true);
+    if constexpr (C == 32) {
+        if (cr < C) {   // the remainder block of a feature: `cr` of its 32 channels exist (blend_fwd_wave.h PARTIAL)
+            FW_LAUNCH_ST(true, true);
+            return;
+        }
+    }
+    if (cstride == C) FW_LAUNCH_ST(false, false);
+    else FW_LAUNCH_ST(true, false);
 #undef FW_LAUNCH_ST
 #undef FW_LAUNCH
 }
@@ -650,13 +679,13 @@ void launch_blend_fwd_wave_rgb(const ViewParams& vp, hipStream_t stream, const I
 {
     const uint32_t nt = vp.grid_x * vp.grid_y;
     const uint32_t fm = fwd_runs_per_xcd();
-    const uint32_t grid = 32u * fwd_runs_longest(nt, fm);
+    const uint32_t grid = 32u * (fm ? fwd_runs_longest(nt, fm) : (img.longest_run ? img.longest_run : xcd_max_run(nt)));
     const FwdZeroFill zf = zfill;
     zfill = FwdZeroFill{nullptr, 0u, nullptr, 0u};
 #define RGB_LAUNCH(XM)                                                                                                                       \
     hipLaunchKernelGGL((blend_fwd_wave_rgb_kernel<EXTRA, XM>), dim3(grid), dim3(64), 0, stream, img.ranges, bin.blend_list, geom.index_rec,   \
                        vp.W, vp.H, vp.grid_x, nt, features, mask, geom.depths, img.final_T, img.n_contrib, img.tile_consumed,                 \
-                       img.tile_nsurv, bg, out_color, out_mask, out_depth, zf, fm)
+                       img.tile_nsurv, bg, out_color, out_mask, out_depth, zf, fm, img.run_bounds)
     if (xm == EXP_HYBRID) RGB_LAUNCH(EXP_HYBRID);
     else if (xm == EXP_EXACT) RGB_LAUNCH(EXP_EXACT);
     else RGB_LAUNCH(EXP_FAST);
@@ -1073,10 +1102,12 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
             if (mask) launch_blend_fwd_wave_rgb<2>(vp, stream, img, bin, geom, feature_ptr, mask, background, out_color, out_mask, out_depth, xm, zfill);
             else launch_blend_fwd_wave_rgb<0>(vp, stream, img, bin, geom, feature_ptr, nullptr, background, out_color, nullptr, nullptr, xm, zfill);
         } else {
-            // feature channels in blocks of 64 / 32 / 16 (one launch per block; see channels_supported)
+            // feature channels in blocks of 64 / 32 (one launch per block; see channels_supported); what is left behind the last whole
+            // block -- 1 .. 31 channels -- is a PARTIAL 32-channel block of the same wave-per-quadrant kernel
             const size_t HW = (size_t)width * height;
             for (int c0 = 0; c0 < channels;) {
-                const int cb = channel_block(channels - c0);
+                const int rem = channels - c0;
+                const int cb = rem >= 64 ? 64 : 32;
                 const float* f = feature_ptr + c0;
                 const float* bgp = background + c0;
                 float* out = out_color + (size_t)c0 * HW;
@@ -1087,7 +1118,7 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
                     else
 #endif
                     launch_blend_fwd_wave<64>(vp, stream, img, bin, geom, f, bgp, out, xm, channels, zfill);
-                } else if (cb == 32) {
+                } else if (rem >= 32) {
 #ifdef MI_RAST_PROFILING
                     if (f32_blend) launch_blend_fwd<32, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels);
                     else if (tile_fwd) launch_blend_fwd_x3<32>(vp, stream, img, bin, geom, f, bgp, out, xexp, channels);
@@ -1095,8 +1126,15 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
 #endif
                     launch_blend_fwd_wave<32>(vp, stream, img, bin, geom, f, bgp, out, xm, channels, zfill);
                 } else {
-                    launch_blend_fwd<16, 0>(vp, stream, img, bin, geom, f, nullptr, bgp, out, nullptr, nullptr, xexp, channels,
-                                            std::min(16, channels - c0));
+#ifdef MI_RAST_PROFILING
+                    // (the comparison kernels have no partial 32-channel form: the tile-batched 16-channel kernel, in one or two blocks)
+                    if (f32_blend || tile_fwd) {
+                        for (int c1 = 0; c1 < rem; c1 += 16)
+                            launch_blend_fwd<16, 0>(vp, stream, img, bin, geom, f + c1, nullptr, bgp + c1, out + (size_t)c1 * HW, nullptr, nullptr, xexp,
+                                                    channels, std::min(16, rem - c1));
+                    } else
+#endif
+                    launch_blend_fwd_wave<32>(vp, stream, img, bin, geom, f, bgp, out, xm, channels, zfill, rem);
                 }
                 c0 += cb;
             }
@@ -1109,7 +1147,8 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
         // A view that will be differentiated (the caller asked for the backward's buffers to be left zeroed): the backward blend's
         // XCD runs from what this forward walked (common.h "WORK-balanced runs"; inside the forward blend's stage time)
         const int nt_all = (int)(vp.grid_x * vp.grid_y);
-        if (((flags & MI_RAST_PREZERO_BWD) || dL_dcolor_next != nullptr) && nt_all <= BIN_MAX_TILES_TOTAL && !(flags & MI_RAST_EQUAL_RUNS))
+        if (((flags & MI_RAST_PREZERO_BWD) || dL_dcolor_next != nullptr) && nt_all <= BIN_MAX_TILES_TOTAL && !(flags & MI_RAST_EQUAL_RUNS) &&
+            knob("MI_RAST_BWD_SCAN", BWD_RUNS_FROM_WALKS))
             hipLaunchKernelGGL(run_bounds_from_walks_kernel, dim3(1), dim3(1024), ((size_t)nt_all + 1) * sizeof(uint32_t), stream, nt_all,
                                img.tile_nsurv, img.run_bounds);
     }

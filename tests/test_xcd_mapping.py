@@ -52,6 +52,11 @@ def bounds_from_walks(nsurv):
     return clamp_runs(b, n)
 
 
+def bounds_from_model(counts, cap, fix):
+    """binning.h: tile_ranges_kernel with run_cap > 0: runs of equal sum(min(list length, cap) + fix)."""
+    return bounds_from_walks(np.minimum(np.asarray(counts, np.int64), cap) + fix - TILE_WEIGHT)
+
+
 def assignment(n, b):
     """-> (items taken by static ids, items in the queues, grid size, takers) for run boundaries b[0..8]."""
     nstatic = 32 * static_len_max(n)
@@ -107,6 +112,12 @@ def test_runs_of_equal_walked_weight():
     _check(n, bounds_from_walks(corner))
     for m in (1, 3, 9, 17):
         _check(m, bounds_from_walks(rng.integers(0, 50, m)))
+    # the range scan's MODEL of the same (before any walk is known): a long list costs what its cap says
+    counts = np.where(np.arange(n) < n // 2, rng.integers(1500, 3000, n), rng.integers(20, 200, n))
+    bm = bounds_from_model(counts, 256, 64)
+    _check(n, bm)
+    wm = np.add.reduceat(np.minimum(counts, 256) + 64, bm[:-1])
+    assert wm.max() <= 1.05 * wm.mean(), wm
 
 
 def fwd_item(wg, n, m):
