@@ -154,7 +154,7 @@ def main():
                          "a comparison kernel of the PROFILING build: run with MI_RAST_LIB=seganygaussians_amd/libmi_rast_prof.so "
                          "(python -m seganygaussians_amd.build --profiling)")
     ap.add_argument("--equal-runs", action="store_true",
-                    help="A/B aid: the backward blend's XCD runs at equal tile counts (MI_RAST_EQUAL_RUNS) instead of work-balanced")
+                    help="A/B aid: the blend kernels' XCD runs at equal tile counts (MI_RAST_EQUAL_RUNS) instead of equal modelled work")
     ap.add_argument("--ref-on-gpu", action="store_true",
                     help="reporting only, after the timed region: also time oracle/_ref (the reference's own kernels, translated "
                          "test-only by oracle/build_ref.py) on the same workload and GPU")

@@ -79,10 +79,11 @@ extern "C" {
                                   backward has run on its buffers since, so the fill command is skipped.  Pass it to ONE backward per forward. */
 #define MI_RAST_F32_BLEND 2    /* 32/64-channel forward on the f32 FMA-chain kernel instead of the exactly split bf16x3
                                   matrix kernel (same alpha/T/n_contrib bit for bit; images agree to a few ulp) */
-#define MI_RAST_EQUAL_RUNS 256 /* A/B aid: a forward that will be differentiated (MI_RAST_PREZERO_BWD or dL_dcolor_next) normally leaves
-                                  WORK-balanced run boundaries for its backward blend -- the eight XCDs' contiguous runs of tiles cut at
-                                  equal sums of what the forward walked (csrc/common.h) --; with this flag it leaves the equal-count
-                                  runs of rounds 2-4.  Results are the same either way (the order of the atomic sums apart) */
+#define MI_RAST_EQUAL_RUNS 256 /* A/B aid: both blend kernels give every XCD (its own L2) one contiguous run of tiles; by default the runs
+                                  are cut at equal MODELLED work -- sum over the tiles of min(list length, 768) + 128, csrc/binning.h:
+                                  tile_ranges_kernel -- because the dispatcher deals workgroups to the XCDs whatever their progress and
+                                  real scenes' density varies over the image; with this flag at equal tile counts (rounds 2-4).
+                                  Results are the same either way (the order of the atomic sums apart) */
 
 /* Replaces std::function<char*(size_t)> (CF/rasterize_points.cu:27-33): must return a device
  * pointer to at least nbytes bytes (256-B aligned), valid until the caller frees it. */

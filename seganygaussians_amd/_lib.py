@@ -16,7 +16,7 @@ MI_BIN_FIELDS = ["entries", "scratch", "blend_list"]
 MI_RAST_FULL_LISTS, MI_RAST_F32_BLEND, MI_RAST_NO_CULL, MI_RAST_FAST_EXP, MI_RAST_VERIFY_LISTS, MI_RAST_TILE_FWD = 1, 2, 4, 8, 16, 32   # `flags` of mi_rast_forward (include/mi_rast.h)
 MI_RAST_PREZERO_BWD = 64   # forward + the one backward of that forward (include/mi_rast.h)
 MI_RAST_EXACT_EXP = 128    # forward blend with expf for every pair instead of the hybrid form (include/mi_rast.h)
-MI_RAST_EQUAL_RUNS = 256   # A/B aid: equal-count XCD runs for the backward blend instead of the work-balanced ones (include/mi_rast.h)
+MI_RAST_EQUAL_RUNS = 256   # A/B aid: XCD runs of equal tile counts in both blend kernels instead of equal modelled work (include/mi_rast.h)
 MI_STAGES = ["preprocess", "depth_sort", "tile_scan", "emit", "tile_sort", "blend_fwd", "blend_bwd", "geom_bwd"]
 
 EXPORTS = [

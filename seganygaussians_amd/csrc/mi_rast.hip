@@ -349,10 +349,13 @@ int channel_block(int rem) { return rem >= 64 ? 64 : (rem >= 32 ? 32 : 16); }
 // How the blend kernels' tiles are dealt to the eight XCDs (common.h, blend_fwd_wave.h: fwd_wave_item, binning.h: tile_ranges_kernel).
 // Product constants; the profiling build reads overrides from the environment for A/B runs (MI_RAST_FWD_RUNS, MI_RAST_RUN_CAP,
 // MI_RAST_RUN_FIX, MI_RAST_BWD_SCAN).
-constexpr int FWD_RUNS_PER_XCD = 1;   // forward: m interleaved runs of equal tile counts per XCD; 0: one run per XCD, boundaries from the range scan
-constexpr int RUN_MODEL_CAP = 0;      // range scan: XCD runs of equal sum(min(list length, cap) + fix); 0: equal tile counts
-constexpr int RUN_MODEL_FIX = 64;
-constexpr int BWD_RUNS_FROM_WALKS = 1;   // forward of a view to be differentiated: the backward's runs from what it walked (one more small launch)
+// Measured in round 5 (profiles/r05_xcd_balance.md; cfg3s = density varying over the image, cfg3 = uniform): equal tile counts 447 / 844
+// views/s; this model 493 / 835 (cap 384 ... 1024, fix 32 ... 128 tried: 768 / 128 best; no cap -- the list length -- 428: a long list
+// on an opaque surface is a SHORT walk); m = 4 interleaved equal-count runs in the forward + the walk scan for the backward 497 / 831.
+constexpr int FWD_RUNS_PER_XCD = 0;   // forward: m interleaved runs of equal tile counts per XCD; 0: one run per XCD, boundaries from the range scan
+constexpr int RUN_MODEL_CAP = 768;    // range scan: XCD runs of equal sum(min(list length, cap) + fix); 0: equal tile counts
+constexpr int RUN_MODEL_FIX = 128;
+constexpr int BWD_RUNS_FROM_WALKS = 0;   // forward of a view to be differentiated: the backward's runs from what it walked (one more 9-us launch)
 inline int knob(const char* name, int dflt)
 {
 #ifdef MI_RAST_PROFILING
@@ -506,7 +509,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         // tile scan 0.058 -> 0.060 ms on cfg3; the fences and the serial tail inside the kernel cost more than the launch they save)
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
-        const uint32_t run_cap = ntiles <= RUN_MODEL_MAX_TILES ? (uint32_t)std::max(0, knob("MI_RAST_RUN_CAP", RUN_MODEL_CAP)) : 0u;
+        const uint32_t run_cap = ntiles <= RUN_MODEL_MAX_TILES && !(flags & MI_RAST_EQUAL_RUNS) ? (uint32_t)std::max(0, knob("MI_RAST_RUN_CAP", RUN_MODEL_CAP)) : 0u;
         const uint32_t run_fix = (uint32_t)std::max(0, knob("MI_RAST_RUN_FIX", RUN_MODEL_FIX));
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024),
                            ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * (run_cap ? 2 : 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor,
@@ -545,7 +548,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
                 else
                     hipLaunchKernelGGL(bin_spans_kernel<true>, dim3(nwg), dim3(BIN_THREADS),
-                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + SPAN_LDS_WORDS) * sizeof(uint32_t), stream, P,
+                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + EMIT_LDS_WORDS) * sizeof(uint32_t), stream, P,
                                        geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1, g_ablate_fwd);
             }
         }

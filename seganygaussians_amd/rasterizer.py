@@ -120,8 +120,7 @@ def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, 
     alpha >= 1/255 decisions differ from the reference's); `verify_lists` (debugging aid) checks that the count and emit passes of the
     lean lists agree slot by slot; `exact_exp` makes the forward blend call expf for every pair (product default: the hybrid form of
     csrc/common.h -- same decisions, alpha to 1e-6): alpha / T / n_contrib / final_T are then bit-identical to a build of the
-    reference's kernels; `equal_runs` (A/B aid) keeps the backward blend's XCD runs at equal tile counts instead of cutting them at
-    equal sums of what the forward walked.  The flags of a
+    reference's kernels; `equal_runs` (A/B aid) keeps the blend kernels' XCD runs at equal tile counts instead of equal modelled work.  The flags of a
     forward are remembered with its buffers and handed to its backward."""
     prev = _opts.flags
     for bit, v in ((_lib.MI_RAST_FULL_LISTS, full_lists), (_lib.MI_RAST_F32_BLEND, f32_blend), (_lib.MI_RAST_NO_CULL, no_cull),
