@@ -104,10 +104,9 @@ constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 constexpr int BIN_MAX_WG = 256;        // workgroups of the count / emit passes (rank slices): one per CU, all resident at once
                                        // (measured 512 / 256 / 128 / 64 slices on cfg3: count + emit 0.167 / 0.146 / 0.199 / 0.349 ms)
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_TILES = 21 * 1024 - 128;  // per launch of the count / emit passes: one LDS cursor per tile + the hand-off arrays (emit:
-                                                // 76 KB, EMIT_LDS_WORDS) must fit in 160 KB; larger images are walked in bands of tile rows
+constexpr int BIN_MAX_TILES = 26 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 57 KB of hand-off
+                                               // arrays must fit in 160 KB; larger images are walked in bands of tile rows
 constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
-constexpr int RUN_MODEL_MAX_TILES = 20 * 1024 - 64;  // ... and, up to this many tiles, the modelled work of the XCD runs beside them
 
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
@@ -123,19 +122,20 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
     // than big_threshold entries are appended to big_list (count in big_list[0], order arbitrary).
     // More than BIN_MAX_TILES_TOTAL items (images beyond 10 Mpx) are walked in segments of that many, one after the other, the
     // running total carried along: ONE pass of the loop below for every image up to 4096 x 2544.
-    // run_cap > 0 (images up to RUN_MODEL_MAX_TILES tiles: one segment): the XCD runs of the blend kernels are cut at equal sums of the
+    // run_cap > 0 (images of one segment): the XCD runs of the blend kernels are cut at equal sums of the
     // MODELLED cost of a tile, min(list length, run_cap) + run_fix -- a list is walked until its pixels are opaque, which takes about
     // run_cap entries where the scene is dense, and to its end where it is sparse; what a walk really covers is only known behind the
-    // forward blend (run_bounds_from_walks_kernel) -- the second prefix sum rides on the first.
-    extern __shared__ uint32_t s_val[];  // [min(ntiles_all, BIN_MAX_TILES_TOTAL) + 1] (+ the same again for the weights when run_cap > 0)
+    // forward blend (run_bounds_from_walks_kernel) -- the second prefix sum rides on the first, at the granularity of the threads'
+    // pieces (registers only); the thread whose piece holds a boundary walks its few tiles.
+    extern __shared__ uint32_t s_val[];  // [min(ntiles_all, BIN_MAX_TILES_TOTAL) + 1]
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_wave_w[16];
     __shared__ uint32_t s_bound[9];
-    const bool weighted = run_bounds != nullptr && run_cap > 0u && ntiles_all <= RUN_MODEL_MAX_TILES;
-    uint32_t* const s_w = s_val + (ntiles_all + 1);
+    const bool weighted = run_bounds != nullptr && run_cap > 0u && ntiles_all <= BIN_MAX_TILES_TOTAL;   // (one segment)
     __shared__ uint32_t s_maxcount;
     __shared__ uint32_t s_nbig;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 9) s_bound[tid] = xcd_run_start((uint32_t)tid, (uint32_t)ntiles_all);   // equal tile counts unless the model says otherwise
     if (tid == 0) {
         s_maxcount = 0;
         s_nbig = 0;
@@ -153,10 +153,7 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
             s_val[i] = sum;  // exclusive prefix inside the piece
             sum += c;
             mx = max(mx, c);
-            if (weighted) {
-                s_w[i] = wsum;
-                wsum += min(c, run_cap) + run_fix;
-            }
+            wsum += min(c, run_cap) + run_fix;
         }
         const uint32_t incl = wave_inclusive_scan(sum, lane);
         const uint32_t incl_w = weighted ? wave_inclusive_scan(wsum, lane) : 0u;
@@ -178,19 +175,35 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
         const uint32_t piece_base = carry + woff + incl - sum;
         for (int i = i0; i < i1; i++) s_val[i] += piece_base;
         if (tid == 0) s_val[ntiles] = carry + total;
+        uint32_t woff_w = 0, total_w = 0;
         if (weighted) {
-            uint32_t woff_w = 0, total_w = 0;
 #pragma unroll
             for (int w = 0; w < 16; w++) {
                 const uint32_t c = s_wave_w[w];
                 woff_w += w < wave ? c : 0u;
                 total_w += c;
             }
-            const uint32_t base_w = woff_w + incl_w - wsum;
-            for (int i = i0; i < i1; i++) s_w[i] += base_w;
-            if (tid == 0) s_w[ntiles] = total_w;
         }
         __syncthreads();
+        if (weighted && total_w > 0u) {
+            // boundary k = first tile i with 8 W(i) >= k W_total, W(i) = modelled work in front of tile i: it lies in (i0, i1] of exactly
+            // one piece -- the one with 8 W(i0) < k W_total <= 8 W(i1) -- whose thread walks its tiles (list lengths = differences of
+            // the finished prefix)
+            const uint64_t w_lo = 8ull * (uint64_t)(woff_w + incl_w - wsum), w_hi = 8ull * (uint64_t)(woff_w + incl_w);
+#pragma unroll
+            for (uint32_t k = 1; k < 8u; k++) {
+                const uint64_t want = (uint64_t)k * (uint64_t)total_w;
+                if (w_lo < want && want <= w_hi) {
+                    uint64_t wacc = w_lo;
+                    int i = i0;
+                    for (; i < i1; i++) {
+                        wacc += 8ull * (uint64_t)(min(s_val[i + 1] - s_val[i], run_cap) + run_fix);
+                        if (wacc >= want) break;
+                    }
+                    s_bound[k] = (uint32_t)min(i + 1, i1);
+                }
+            }
+        }
         for (int i = tid; i < ntiles; i += 1024) {
             const uint32_t lo = s_val[i], hi = s_val[i + 1];
             ranges[seg0 + i] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);
@@ -205,22 +218,7 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
         __syncthreads();   // s_val / s_wave are rewritten by the next segment
     }
     if (run_bounds != nullptr) {
-        const uint32_t n = (uint32_t)ntiles_all;
-        if (tid >= 1 && tid <= 7) {
-            uint32_t bk = xcd_run_start((uint32_t)tid, n);
-            if (weighted) {   // first tile i with 8 W(i) >= k W_total, W(i) = modelled work in front of tile i (s_w: still this segment's)
-                const uint64_t want = (uint64_t)tid * (uint64_t)s_w[n];
-                uint32_t lo = 0, hi = n;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (8ull * (uint64_t)s_w[mid] >= want) hi = mid;
-                    else lo = mid + 1;
-                }
-                bk = lo;
-            }
-            s_bound[tid] = bk;
-        }
-        __syncthreads();
+        const uint32_t n = (uint32_t)ntiles_all;   // (s_bound: behind the barrier that ends the segment loop)
         if (tid == 0) {   // the clamp in registers (xcd_clamp_runs on LDS words would be seven dependent round trips)
             uint32_t bb[9];
 #pragma unroll
@@ -514,14 +512,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
 // Measured on cfg3: 8.68 M tiles in the shrunk rects, 5.2 M in the spans; the enumerating emit pass spent 182 VALU
 // instructions per 64 rect tiles on the whole-tile test and 386 per 64 survivors on the four quadrant tests.
 // Slices (rank chunks dealt round robin), partial[][] and the cursors are those of bin_count_kernel / bin_ranks_kernel.
-// Row items per window.  COUNT walks them 1024 at a time (no barrier inside its window loop); EMIT takes SPAN_WIN = 2048 per window, two
-// per thread: a window is three workgroup-barrier phases of ~1 us each whatever it holds (round 5), and a round of 1024 Gaussians
-// yields ~2200 row items on cfg3 (three windows of 1024, the last one nearly empty) and ~1800 on cfg5.
-constexpr int SPAN_WIN = 2048;
-constexpr int SPAN_LDS_WORDS = 3088 + 2048 + 4096 + 5 * 1024;  // COUNT: RectWork + means + conics + prefix / rect / radius (+ 2 unused)
-// EMIT: means + conics + prefix / rect / radius, then per span of the window: prefix, rect x, rect y, the two bands' columns
-constexpr int EMIT_LDS_WORDS = 2048 + 4096 + 3 * 1024 + 5 * SPAN_WIN + 64;
-static_assert((BIN_MAX_TILES + 4 + EMIT_LDS_WORDS) * 4 <= 160 * 1024, "cursors + hand-off arrays of the emit pass exceed the LDS of a CU");
+constexpr int SPAN_LDS_WORDS = 3088 + 2048 + 4096 + 5 * 1024;  // RectWork + means + conics + prefix / rect / tau-free params
 
 __device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid, uint32_t* s_wsum, uint32_t& total)
 {
@@ -560,19 +551,15 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
     const int head = EMIT ? ((ntiles + 3) & ~3) : (((int)gy * stride + 3) & ~3);
     uint32_t* s_cnt = s_dyn;
     int* s_grid = reinterpret_cast<int*>(s_dyn);
-    uint32_t* s_base = s_dyn + head;
-    // (the two passes lay their hand-off arrays out differently: EMIT keeps SPAN_WIN spans per window)
-    float2* s_xy = reinterpret_cast<float2*>(s_base + (EMIT ? 0 : 3088));
-    float4* s_co = reinterpret_cast<float4*>(s_base + (EMIT ? 2048 : 3088 + 2048));
-    uint32_t* s_gpre = s_base + (EMIT ? 6144 : 3088 + 6144);   // inclusive prefix of the Gaussians' row counts
-    uint32_t* s_grect = s_gpre + 1024;                         // clip columns x0 | x1 << 10, first row << 21
-    uint32_t* s_grad = s_grect + 1024;                         // radius (the margin of tau needs it)
-    uint32_t* s_wsum = EMIT ? s_grad + 1024 : s_base + 3072;   // [64] wave totals of the workgroup scans
-    uint32_t* s_sp = s_grad + 1024 + 64;                       // EMIT, per span of the window [SPAN_WIN]: inclusive prefix of the widths
-    uint32_t* s_sx = s_sp + SPAN_WIN;                          //   first tile column | width << 16
-    uint32_t* s_sy = s_sx + SPAN_WIN;                          //   tile row
-    uint32_t* s_q0 = s_sy + SPAN_WIN;                          //   upper band's columns lo | hi << 11, Gaussian slot << 22
-    uint32_t* s_q1 = s_q0 + SPAN_WIN;                          //   lower band's columns lo | hi << 11
+    uint32_t* s_rw = s_dyn + head;
+    RectWork rw{s_rw, s_rw + 1024, s_rw + 2048, s_rw + 3072};
+    float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);
+    float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);
+    uint32_t* s_gpre = s_rw + 3088 + 6144;   // inclusive prefix of the Gaussians' row counts
+    uint32_t* s_grect = s_gpre + 1024;       // clip columns x0 | x1 << 10, first row << 21
+    uint32_t* s_grad = s_grect + 1024;       // radius (the margin of tau needs it)
+    uint32_t* s_q0 = s_grad + 1024;          // EMIT, per span: upper band's columns lo | hi << 11, Gaussian slot << 22
+    uint32_t* s_q1 = s_q0 + 1024;            //                 lower band's columns lo | hi << 11
     uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * ntiles_all + tile0;
     if (EMIT) {
         for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
@@ -586,28 +573,6 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
     // and LDS searches with one workgroup per CU: nothing else would hide the load).  Unconditional, index clamped: a
     // conditionally assigned load result is waited for on the spot.
     BlendRec nxt = rank_rec[min((wave * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
-    // One row item k of the round: the two closed-form column intervals of its tile row and the tile span that holds them.
-    // Returns the span's width in tiles (0: nothing to list); g = the Gaussian's slot in the round.
-    auto row_item = [&](uint32_t k, uint32_t& g_out, uint32_t& ty_out, int& lo0, int& hi0, int& lo1, int& hi1, uint32_t& x0) -> uint32_t {
-        int g = 0;  // first Gaussian slot with prefix > k
-#pragma unroll
-        for (int step = 512; step >= 1; step >>= 1)
-            if (s_gpre[g + step - 1] <= k) g += step;
-        const uint32_t prev = g == 0 ? 0u : s_gpre[g - 1];
-        const uint32_t packed = s_grect[g];
-        const uint32_t cx0 = packed & 1023u, cx1 = (packed >> 10) & 2047u, ty = (packed >> 21) + (k - prev);
-        const float2 xy = s_xy[g];
-        const SpanPre pre = span_prepare(s_co[g], (int)s_grad[g]);
-        band_columns(pre, xy, (float)(ty * TILE_Y), (int)(2u * cx0), (int)(2u * cx1), lo0, hi0);
-        band_columns(pre, xy, (float)(ty * TILE_Y + 8u), (int)(2u * cx0), (int)(2u * cx1), lo1, hi1);
-        g_out = (uint32_t)g;
-        ty_out = ty;
-        if (!(hi0 > lo0 || hi1 > lo1)) return 0u;
-        const int lo = hi0 > lo0 ? (hi1 > lo1 ? min(lo0, lo1) : lo0) : lo1;
-        const int hi = hi0 > lo0 ? (hi1 > lo1 ? max(hi0, hi1) : hi0) : hi1;
-        x0 = (uint32_t)lo >> 1;
-        return (((uint32_t)hi + 1u) >> 1) - x0;
-    };
     for (int it = 0; it < rounds; it++) {
         const int r = ((it * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
         const BlendRec rec = nxt;
@@ -631,95 +596,71 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
             }
         }
         uint32_t rows_total;
-        s_gpre[tid] = workgroup_inclusive_scan(h, tid, s_wsum, rows_total);
+        s_gpre[tid] = workgroup_inclusive_scan(h, tid, rw.wsum, rows_total);
         __syncthreads();
         if MI_ABLATE(1 << 20) rows_total = 0;
-        if constexpr (!EMIT) {
-            for (uint32_t w0 = 0; w0 < rows_total; w0 += 1024) {  // windows of 1024 (Gaussian, tile row) items; no barrier in here
-                const uint32_t k = w0 + (uint32_t)tid;
-                if (k >= rows_total) continue;
-                uint32_t g, ty, x0 = 0;
+        for (uint32_t w0 = 0; w0 < rows_total; w0 += 1024) {  // windows of 1024 (Gaussian, tile row) items
+            const uint32_t k = w0 + (uint32_t)tid;
+            uint2 smin = make_uint2(0, 0), smax = make_uint2(0, 0);
+            uint32_t width = 0;
+            if (k < rows_total) {
+                int g = 0;  // first Gaussian slot with prefix > k
+#pragma unroll
+                for (int step = 512; step >= 1; step >>= 1)
+                    if (s_gpre[g + step - 1] <= k) g += step;
+                const uint32_t prev = g == 0 ? 0u : s_gpre[g - 1];
+                const uint32_t packed = s_grect[g];
+                const uint32_t cx0 = packed & 1023u, cx1 = (packed >> 10) & 2047u, ty = (packed >> 21) + (k - prev);
+                const float2 xy = s_xy[g];
+                const SpanPre pre = span_prepare(s_co[g], (int)s_grad[g]);
                 int lo0, hi0, lo1, hi1;
-                const uint32_t width = row_item(k, g, ty, lo0, hi0, lo1, hi1, x0);
-                if (width == 0u) continue;
-                // EXACT counts: a tile is counted iff one of the two intervals has a column in it, i.e. iff the emit
-                // pass finds a non-zero mask there -- the two bands' tile ranges separately when a gap lies between them
-                int* row = s_grid + (ty - by0) * stride;
-                const int a0 = lo0 >> 1, b0 = (hi0 + 1) >> 1, a1 = lo1 >> 1, b1 = (hi1 + 1) >> 1;
-                if (hi0 > lo0 && hi1 > lo1 && (b0 < a1 || b1 < a0)) {
-                    atomicAdd(&row[a0], 1);
-                    atomicAdd(&row[b0], -1);
-                    atomicAdd(&row[a1], 1);
-                    atomicAdd(&row[b1], -1);
-                } else {
-                    atomicAdd(&row[x0], 1);
-                    atomicAdd(&row[x0 + width], -1);
+                band_columns(pre, xy, (float)(ty * TILE_Y), (int)(2u * cx0), (int)(2u * cx1), lo0, hi0);
+                band_columns(pre, xy, (float)(ty * TILE_Y + 8u), (int)(2u * cx0), (int)(2u * cx1), lo1, hi1);
+                if (hi0 > lo0 || hi1 > lo1) {
+                    const int lo = hi0 > lo0 ? (hi1 > lo1 ? min(lo0, lo1) : lo0) : lo1;
+                    const int hi = hi0 > lo0 ? (hi1 > lo1 ? max(hi0, hi1) : hi0) : hi1;
+                    smin = make_uint2((uint32_t)lo >> 1, ty);
+                    smax = make_uint2(((uint32_t)hi + 1u) >> 1, ty + 1u);
+                    width = smax.x - smin.x;
+                    if (EMIT) {
+                        s_q0[tid] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | ((uint32_t)g << 22);
+                        s_q1[tid] = (uint32_t)lo1 | ((uint32_t)hi1 << 11);
+                    } else {
+                        // EXACT counts: a tile is counted iff one of the two intervals has a column in it, i.e. iff the emit
+                        // pass finds a non-zero mask there -- the two bands' tile ranges separately when a gap lies between them
+                        int* row = s_grid + (ty - by0) * stride;
+                        const int a0 = lo0 >> 1, b0 = (hi0 + 1) >> 1, a1 = lo1 >> 1, b1 = (hi1 + 1) >> 1;
+                        if (hi0 > lo0 && hi1 > lo1 && (b0 < a1 || b1 < a0)) {
+                            atomicAdd(&row[a0], 1);
+                            atomicAdd(&row[b0], -1);
+                            atomicAdd(&row[a1], 1);
+                            atomicAdd(&row[b1], -1);
+                        } else {
+                            atomicAdd(&row[smin.x], 1);
+                            atomicAdd(&row[smax.x], -1);
+                        }
+                    }
                 }
             }
-        } else {
-            for (uint32_t w0 = 0; w0 < rows_total; w0 += SPAN_WIN) {  // windows of SPAN_WIN row items: span j * 1024 + tid <-> item w0 + j * 1024 + tid
-                uint32_t width[SPAN_WIN / 1024];
-#pragma unroll
-                for (int j = 0; j < SPAN_WIN / 1024; j++) {
-                    const uint32_t k = w0 + 1024u * (uint32_t)j + (uint32_t)tid;
-                    width[j] = 0u;
-                    uint32_t g = 0, ty = 0, x0 = 0;
-                    int lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
-                    if (k < rows_total) width[j] = row_item(k, g, ty, lo0, hi0, lo1, hi1, x0);
-                    const int sp = 1024 * j + tid;
-                    s_sx[sp] = x0 | (width[j] << 16);
-                    s_sy[sp] = ty;
-                    s_q0[sp] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | (g << 22);
-                    s_q1[sp] = (uint32_t)lo1 | ((uint32_t)hi1 << 11);
-                }
-                if MI_ABLATE(1 << 16) continue;
-                // ---- second level: the tiles of the window's spans, balanced over the workgroup (binary search in the prefix of the
-                // widths): one scan over all SPAN_WIN widths -- block j behind block j - 1 -- with ONE barrier between the wave
-                // totals and their use
-                uint32_t incl[SPAN_WIN / 1024];
-#pragma unroll
-                for (int j = 0; j < SPAN_WIN / 1024; j++) {
-                    incl[j] = wave_inclusive_scan(width[j], lane);
-                    if (lane == 63) s_wsum[16 * j + wave] = incl[j];
-                }
-                __syncthreads();
-                uint32_t total = 0;
-#pragma unroll
-                for (int j = 0; j < SPAN_WIN / 1024; j++) {
-                    uint32_t woff = 0, tot = 0;
-#pragma unroll
-                    for (int w = 0; w < 16; w++) {
-                        const uint32_t c = s_wsum[16 * j + w];
-                        woff += w < wave ? c : 0u;
-                        tot += c;
-                    }
-                    s_sp[1024 * j + tid] = total + woff + incl[j];
-                    total += tot;
-                }
-                __syncthreads();
-                for (uint32_t i = (uint32_t)tid; i < total; i += 1024) {
-                    if MI_ABLATE(1 << 17) break;
-                    int o = 0;   // first span with prefix > i
-#pragma unroll
-                    for (int step = SPAN_WIN / 2; step >= 1; step >>= 1)
-                        if (s_sp[o + step - 1] <= i) o += step;
-                    const uint32_t sx = s_sx[o];
-                    const uint32_t tx = (sx & 0xFFFFu) + (i - (o == 0 ? 0u : s_sp[o - 1])), ty = s_sy[o];
-                    const uint32_t q0 = s_q0[o], q1 = s_q1[o];
-                    const uint32_t lo0 = q0 & 2047u, n0 = ((q0 >> 11) & 2047u) - lo0, lo1 = q1 & 2047u, n1 = ((q1 >> 11) & 2047u) - lo1;
-                    const uint32_t c = 2u * tx;
-                    const uint32_t qmask = (uint32_t)(c - lo0 < n0) | ((uint32_t)(c + 1u - lo0 < n0) << 1) |
-                                           ((uint32_t)(c - lo1 < n1) << 2) | ((uint32_t)(c + 1u - lo1 < n1) << 3);
-                    if (qmask != 0u) {
-                        const uint32_t slot_g = q0 >> 22;
-                        const uint32_t rank = (uint32_t)(((it * 16 + (int)(slot_g >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(slot_g & 63u));
-                        if MI_ABLATE(1 << 18) continue;
-                        const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
-                        if MI_ABLATE(1 << 19) continue;
-                        entries[slot] = rank | (qmask << RANK_BITS);
-                    }
-                }
-                __syncthreads();  // the span arrays are rewritten by the next window
+            if (EMIT && !MI_ABLATE(1 << 16)) {
+                for_each_tile_balanced(
+                    rw, tid, smin, smax, width,
+                    [&](uint32_t owner, uint32_t tx, uint32_t ty) {
+                        if MI_ABLATE(1 << 17) return;
+                        const uint32_t q0 = s_q0[owner], q1 = s_q1[owner];
+                        const uint32_t lo0 = q0 & 2047u, n0 = ((q0 >> 11) & 2047u) - lo0, lo1 = q1 & 2047u, n1 = ((q1 >> 11) & 2047u) - lo1;
+                        const uint32_t c = 2u * tx;
+                        const uint32_t qmask = (uint32_t)(c - lo0 < n0) | ((uint32_t)(c + 1u - lo0 < n0) << 1) |
+                                               ((uint32_t)(c - lo1 < n1) << 2) | ((uint32_t)(c + 1u - lo1 < n1) << 3);
+                        if (qmask != 0u) {
+                            const uint32_t slot_g = q0 >> 22;
+                            const uint32_t rank = (uint32_t)(((it * 16 + (int)(slot_g >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(slot_g & 63u));
+                            if MI_ABLATE(1 << 18) return;
+                            const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
+                            if MI_ABLATE(1 << 19) return;
+                            entries[slot] = rank | (qmask << RANK_BITS);
+                        }
+                    });
             }
         }
         __syncthreads();  // the Gaussian arrays are rewritten by the next round

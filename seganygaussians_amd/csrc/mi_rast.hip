@@ -509,10 +509,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         // tile scan 0.058 -> 0.060 ms on cfg3; the fences and the serial tail inside the kernel cost more than the launch they save)
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
-        const uint32_t run_cap = ntiles <= RUN_MODEL_MAX_TILES && !(flags & MI_RAST_EQUAL_RUNS) ? (uint32_t)std::max(0, knob("MI_RAST_RUN_CAP", RUN_MODEL_CAP)) : 0u;
+        const uint32_t run_cap = !(flags & MI_RAST_EQUAL_RUNS) ? (uint32_t)std::max(0, knob("MI_RAST_RUN_CAP", RUN_MODEL_CAP)) : 0u;
         const uint32_t run_fix = (uint32_t)std::max(0, knob("MI_RAST_RUN_FIX", RUN_MODEL_FIX));
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024),
-                           ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * (run_cap ? 2 : 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor,
+                           ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor,
                            img.ranges, img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr,
                            g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds, run_cap, run_fix);
     }
@@ -548,7 +548,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
                 else
                     hipLaunchKernelGGL(bin_spans_kernel<true>, dim3(nwg), dim3(BIN_THREADS),
-                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + EMIT_LDS_WORDS) * sizeof(uint32_t), stream, P,
+                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + SPAN_LDS_WORDS) * sizeof(uint32_t), stream, P,
                                        geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1, g_ablate_fwd);
             }
         }
