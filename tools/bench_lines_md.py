@@ -14,7 +14,7 @@ out = [f"# Bench lines of the final round build ({tag})",
        "`--ref-on-gpu` adds `reference_on_gpu` (oracle/_ref = the reference's own kernels, hipify-perl at build time, timed on the same workload "
        "and GPU after the timed region).  `timing` = median / p10 / p90 over 20 untimed blocks of ten steps; `roofline.traffic` / `alu` are shown "
        "only when the committed PMC summary carries the stamp of the library being timed (`roofline.library`).", ""]
-summary = ["| run | views/s | sustained views/s (>= 2 s back to back) | ms/step | median (p10..p90) | dominant kernel: frac | whole view: frac / without replaced / by traffic |", "|---|---|---|---|---|---|---|"]
+summary = ["| run | views/s | sustained views/s (>= 2 s back to back) | ms/step | median (p10..p90) | dominant kernel: frac | whole view: frac (replaced stages left out) / by SURVEY bytes / by traffic |", "|---|---|---|---|---|---|---|"]
 for name, cmd in runs:
     path = os.path.join(src, name + ".log")
     if not os.path.exists(path):
