@@ -56,6 +56,12 @@ namespace mirast {
 #ifndef MI_BWD_DEFER
 #define MI_BWD_DEFER 0
 #endif
+// MI_BWD_NOMFMA (round 5, timing proxy, wrong results): every v_mfma_f32_16x16x4_f32 of the three contractions replaced by ONE v_fma_f32
+// on the same operands -- the issue time of 80 VALU instructions per chunk instead of 80 x 32 cycles on the f32 matrix pipe: a lower
+// bound for what contractions on the bf16 pipe would issue (profiles/r05_bwd_ablation.md)
+#ifndef MI_BWD_NOMFMA
+#define MI_BWD_NOMFMA 0
+#endif
 // 1 / x to ~0.5 ulp: v_rcp_f32 (1 ulp) plus one Newton step (two FMAs).  T is divided by (1 - alpha) once per row and the
 // quotients are chained through the whole list: the reference uses a correctly rounded division there (backward.cu:487).
 #ifndef MI_BWD_RCP_REFINE
@@ -413,7 +419,8 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
             for (int s = 0; s < CPL; s++)
 #pragma unroll
                 for (int pb = 0; pb < 4; pb++)
-                    sacc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], dLB[pb][s], sacc[pb], 0, 0, 0);
+                    if constexpr (MI_BWD_NOMFMA) sacc[pb][0] = fmaf(fa[s], dLB[pb][s], sacc[pb][0]);   // timing proxy: one VALU FMA in place of the MFMA (wrong results)
+                    else sacc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], dLB[pb][s], sacc[pb], 0, 0, 0);
         }
         // Transpose to lane = pixel through LDS: lane 16g+p holds row 4g+r of pixel 16pb+p in sacc[pb][r]; writes and row
         // reads are conflict-free (row stride 68 floats).  Row m of S is read when step 4 reaches row m, just before w of
@@ -571,7 +578,8 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
                     const int s = 4 * s4 + t;
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++)
-                        facc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[nb][s], facc[nb], 0, 0, 0);
+                        if constexpr (MI_BWD_NOMFMA) facc[nb][0] = fmaf(wa[t], dLT[nb][s], facc[nb][0]);
+                        else facc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[nb][s], facc[nb], 0, 0, 0);
                     if constexpr (MI_BWD_SEPMOM) {
                         if (s4 < 2) {
                             const float x = (float)s - 3.5f;  // s = 0..7: the pixel column
@@ -582,7 +590,8 @@ __global__ void __launch_bounds__(64 * WPB, BwvCfg<C>::WAVES) blend_bwd_wave_ker
                     } else {
                         const float x = (float)(s & 7) - 3.5f;
                         const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
-                        macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
+                        if constexpr (MI_BWD_NOMFMA) macc[0] = fmaf(ua[t], phi, macc[0]);
+                        else macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
                     }
                 }
             }
