@@ -18,7 +18,7 @@ from tests import helpers as hp  # noqa: E402
 
 
 def one_case(rng, k, run=True, diagnose=False):
-    C = int(rng.choice([3, 3, 32, 32, 64, 16, 48, 96, 128]))   # channel blocks: 48 = 32 + 16, 96 = 64 + 32, 128 = 64 + 64
+    C = int(rng.choice([3, 3, 32, 32, 64, 16, 48, 96, 128, 5, 20, 40, 100]))   # channel blocks: 48 = 32 + 16 of 32, 96 = 64 + 32, 128 = 64 + 64, 100 = 64 + 32 + 4 of 32
     W, H = int(rng.integers(17, 420)), int(rng.integers(17, 300))
     P = int(rng.choice([1, 7, 300, 3000, 20000, 60000]))
     with_shs = bool(C == 3 and rng.random() < 0.5)
