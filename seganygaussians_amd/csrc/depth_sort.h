@@ -200,8 +200,7 @@ __global__ void __launch_bounds__(256) depth_bucket_sort_wave_kernel(const uint2
                                                                      const uint2* __restrict__ pairs,
                                                                      const BlendRec* __restrict__ index_rec,
                                                                      uint32_t* __restrict__ sorted_idx,
-                                                                     BlendRec* __restrict__ rank_rec,
-                                                                     const int* __restrict__ r_slots, int idx_bits)
+                                                                     BlendRec* __restrict__ rank_rec)
 {
     __shared__ uint32_t s_k[4][DS_WAVE];
     __shared__ uint32_t s_v[4][DS_WAVE];
@@ -212,61 +211,31 @@ __global__ void __launch_bounds__(256) depth_bucket_sort_wave_kernel(const uint2
     const int n = (int)(range.y - range.x);
     if (n == 0 || n > DS_WAVE) return;  // longer buckets are on the big-bucket list
     constexpr int EPL = DS_WAVE / 64;   // elements per lane
-    // Inside a bucket only the low `shift` bits of the key differ (the bucket is its high bits): when those and the index fit one
-    // word -- shift + idx_bits <= 32: every view of up to ~2 M Gaussians -- the pairs are ranked as 32-bit words
-    // (key low bits << idx_bits | index): half the LDS reads and a 32-bit compare per pair of pairs.  Wave-uniform choice.
-    const int shift = depth_map(r_slots).shift;
-    const bool packed = shift + idx_bits <= 32;
+    uint64_t mine[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; t++) {
+        const int e = lane + 64 * t;
+        uint2 p = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (e < n) {
+            p = pairs[range.x + e];
+            s_k[wave][e] = p.x;
+            s_v[wave][e] = p.y;
+        }
+        mine[t] = ((uint64_t)p.x << 32) | p.y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     int rank[EPL];
 #pragma unroll
     for (int t = 0; t < EPL; t++) rank[t] = 0;
-    uint32_t idx[EPL];
-    if (packed) {
-        const uint32_t kmask = shift >= 32 ? 0xFFFFFFFFu : ((1u << shift) - 1u);
-        uint32_t mine[EPL];
+    for (int q = 0; q < n; q++) {
+        const uint64_t other = ((uint64_t)s_k[wave][q] << 32) | s_v[wave][q];
 #pragma unroll
-        for (int t = 0; t < EPL; t++) {
-            const int e = lane + 64 * t;
-            mine[t] = 0xFFFFFFFFu;
-            idx[t] = 0u;
-            if (e < n) {
-                const uint2 p = pairs[range.x + e];
-                idx[t] = p.y;
-                mine[t] = idx_bits >= 32 ? p.y : (((p.x & kmask) << idx_bits) | p.y);
-                s_k[wave][e] = mine[t];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        for (int q = 0; q < n; q++) {
-            const uint32_t other = s_k[wave][q];
-#pragma unroll
-            for (int t = 0; t < EPL; t++) rank[t] += other < mine[t] ? 1 : 0;
-        }
-    } else {
-        uint64_t mine[EPL];
-#pragma unroll
-        for (int t = 0; t < EPL; t++) {
-            const int e = lane + 64 * t;
-            uint2 p = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-            if (e < n) {
-                p = pairs[range.x + e];
-                s_k[wave][e] = p.x;
-                s_v[wave][e] = p.y;
-            }
-            idx[t] = p.y;
-            mine[t] = ((uint64_t)p.x << 32) | p.y;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        for (int q = 0; q < n; q++) {
-            const uint64_t other = ((uint64_t)s_k[wave][q] << 32) | s_v[wave][q];
-#pragma unroll
-            for (int t = 0; t < EPL; t++) rank[t] += other < mine[t] ? 1 : 0;
-        }
+        for (int t = 0; t < EPL; t++) rank[t] += other < mine[t] ? 1 : 0;
     }
 #pragma unroll
     for (int t = 0; t < EPL; t++) {
         if (lane + 64 * t < n) {
-            const uint32_t g = idx[t];
+            const uint32_t g = (uint32_t)mine[t];
             rank_rec[range.x + rank[t]] = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
             sorted_idx[range.x + rank[t]] = g;
         }

@@ -473,7 +473,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         hipLaunchKernelGGL(depth_bucket_kernel<true>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
                            geom.depth_key, ds.partial, ds.ranges, ds.pairs, geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
         hipLaunchKernelGGL(depth_bucket_sort_wave_kernel, dim3((DS_NB + 3) / 4), dim3(256), 0, stream, ds.ranges, ds.pairs,
-                           geom.index_rec, geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered, idx_bits);
+                           geom.index_rec, geom.sorted_idx, geom.rank_rec);
         hipLaunchKernelGGL((depth_bucket_sort_kernel<DS_WAVE, DS_LARGE, true>), dim3(2048), dim3(256), 0, stream, ds.ranges,
                            ds.big_list, ds.pairs, ds.pairs_tmp, idx_passes, geom.index_rec,
                            geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
