@@ -51,14 +51,15 @@ __device__ __forceinline__ uint32_t slice_row(uint32_t b, uint32_t nwg)
 }
 
 struct RectWork {
-    uint32_t* prefix;  // LDS [1024] inclusive prefix of counts
-    uint32_t* rx;      // LDS [1024] rect_min.x | width << 16
-    uint32_t* ry;      // LDS [1024] rect_min.y
+    uint32_t* prefix;  // LDS [NT] inclusive prefix of counts
+    uint32_t* rx;      // LDS [NT] rect_min.x | width << 16
+    uint32_t* ry;      // LDS [NT] rect_min.y
     uint32_t* wsum;    // LDS [16]
 };
 
-// Contains workgroup barriers: call from all 1024 threads.  f(owner_thread, tile_x, tile_y) handles one item.
-template <typename F>
+// Contains workgroup barriers: call from all NT threads (NT = 1024, or 512: two workgroups per CU).  f(owner_thread, tile_x, tile_y)
+// handles one item.
+template <int NT = 1024, typename F>
 __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int tid, uint2 rmin, uint2 rmax, uint32_t count, F&& f)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -67,7 +68,7 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
     __syncthreads();
     uint32_t woff = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
+    for (int w = 0; w < NT / 64; w++) {
         const uint32_t c = rw.wsum[w];
         woff += w < wave ? c : 0u;
         total += c;
@@ -77,11 +78,11 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
     rw.rx[tid] = rmin.x | ((rmax.x - rmin.x) << 16);
     rw.ry[tid] = rmin.y;
     __syncthreads();
-    for (uint32_t k = (uint32_t)tid; k < total; k += 1024) {
+    for (uint32_t k = (uint32_t)tid; k < total; k += NT) {
         // first thread o with prefix[o] > k
         int lo = 0;
 #pragma unroll
-        for (int step = 512; step >= 1; step >>= 1)
+        for (int step = NT / 2; step >= 1; step >>= 1)
             if (rw.prefix[lo + step - 1] <= k) lo += step;
         const uint32_t packed = rw.rx[lo];
         const uint32_t w = packed >> 16, x0 = packed & 0xFFFFu, y0 = rw.ry[lo];
@@ -326,32 +327,9 @@ __device__ __forceinline__ BlendRec list_record(const uint32_t* __restrict__ lst
 }
 
 // ---- per-rank geometry records ------------------------------------------------------------------------
-// After the depth sort, the per-Gaussian data the binning stages need (pixel mean, conic, opacity, radius, id)
-// is permuted ONCE into rank order as 32-byte records.  Rank emission then reads them coalesced, and the per-tile
-// sort gathers ONE 32-byte sector per list entry at monotonically increasing addresses instead of three dependent
-// random gathers (sorted_idx -> means2D -> conic_opacity; measured: that gather, not the radix passes, was 0.3 of
-// the 0.34 ms of the tile sort kernel).  The record layout is the blend record's; `pm` holds the radius here.
-__global__ void __launch_bounds__(256) build_rank_records_kernel(int P, const uint32_t* __restrict__ sorted_idx,
-                                                                 const float2* __restrict__ points_xy,
-                                                                 const float4* __restrict__ conic_opacity,
-                                                                 const int* __restrict__ radii, BlendRec* __restrict__ rank_rec)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t g = sorted_idx[r];
-    const int rad = radii[g];
-    BlendRec rec;
-    rec.id = g;
-    rec.pm = (uint32_t)(rad > 0 ? rad : 0);
-    if (rad > 0) {
-        rec.xy = points_xy[g];
-        rec.co = conic_opacity[g];
-    } else {
-        rec.xy = make_float2(0.f, 0.f);
-        rec.co = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    rank_rec[r] = rec;
-}
+// The per-Gaussian data the binning stages need (pixel mean, conic, opacity, radius, id) is written by the preprocess pass as ONE
+// 32-byte record per Gaussian (index_rec) and permuted once into depth-rank order by the depth sort (rank_rec, depth_sort.h): the count
+// and emit passes read the ranks coalesced; the blend kernels gather index_rec[id] per list entry they reach.
 
 // ---- 4. counting and rank emission -------------------------------------------------------------------
 // Global atomics are the scarce resource of the binning stages (about 25 G scattered dword atomics/s on this part:
@@ -512,8 +490,22 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
 // Measured on cfg3: 8.68 M tiles in the shrunk rects, 5.2 M in the spans; the enumerating emit pass spent 182 VALU
 // instructions per 64 rect tiles on the whole-tile test and 386 per 64 survivors on the four quadrant tests.
 // Slices (rank chunks dealt round robin), partial[][] and the cursors are those of bin_count_kernel / bin_ranks_kernel.
-constexpr int SPAN_LDS_WORDS = 3088 + 2048 + 4096 + 5 * 1024;  // RectWork + means + conics + prefix / rect / tau-free params
+// LDS words of the hand-off arrays of a workgroup of nt threads: RectWork + means + conics + prefix / rect / radius / two bands' columns
+__host__ __device__ constexpr int span_lds_words(int nt) { return (3 * nt + 16) + 2 * nt + 4 * nt + 5 * nt; }
+constexpr int SPAN_LDS_WORDS = span_lds_words(1024);
+// Threads per workgroup of the LEAN count / emit passes.  512: two workgroups share a CU (2 x 61 KB of LDS at 1080p) and overlap each
+// other's workgroup-barrier phases -- the passes are chains of such phases at ~1 us each --, at the price of twice
+// as many rank slices (the partial[][] table and its scan double).  Measured in round 5: profiles/r05_front_half.md.
+constexpr int BIN_LEAN_THREADS = 512;
+constexpr int BIN_LEAN_MAX_WG = 512;
+inline int bin_lean_workgroups(int P, int nt)
+{
+    const int blocks = (P + nt - 1) / nt;
+    const int cap = nt == 1024 ? BIN_MAX_WG : BIN_LEAN_MAX_WG;
+    return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+}
 
+template <int NT = 1024>
 __device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid, uint32_t* s_wsum, uint32_t& total)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -523,7 +515,7 @@ __device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid
     __syncthreads();
     uint32_t woff = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
+    for (int w = 0; w < NT / 64; w++) {
         const uint32_t c = s_wsum[w];
         woff += w < wave ? c : 0u;
         tot += c;
@@ -532,8 +524,8 @@ __device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid
     return incl + woff;
 }
 
-template <bool EMIT>
-__global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const BlendRec* __restrict__ rank_rec,
+template <bool EMIT, int NT = 1024>
+__global__ void __launch_bounds__(NT) bin_spans_kernel(int P, const BlendRec* __restrict__ rank_rec,
                                                                 uint32_t* __restrict__ partial,
                                                                 const uint2* __restrict__ ranges,
                                                                 uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy_all,
@@ -552,31 +544,33 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
     uint32_t* s_cnt = s_dyn;
     int* s_grid = reinterpret_cast<int*>(s_dyn);
     uint32_t* s_rw = s_dyn + head;
-    RectWork rw{s_rw, s_rw + 1024, s_rw + 2048, s_rw + 3072};
-    float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);
-    float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);
-    uint32_t* s_gpre = s_rw + 3088 + 6144;   // inclusive prefix of the Gaussians' row counts
-    uint32_t* s_grect = s_gpre + 1024;       // clip columns x0 | x1 << 10, first row << 21
-    uint32_t* s_grad = s_grect + 1024;       // radius (the margin of tau needs it)
-    uint32_t* s_q0 = s_grad + 1024;          // EMIT, per span: upper band's columns lo | hi << 11, Gaussian slot << 22
-    uint32_t* s_q1 = s_q0 + 1024;            //                 lower band's columns lo | hi << 11
+    constexpr int NW = NT / 64;              // waves per workgroup
+    static_assert(NT == 1024 || NT == 512, "rank slices are dealt in 64-rank chunks to 16 or 8 waves");
+    RectWork rw{s_rw, s_rw + NT, s_rw + 2 * NT, s_rw + 3 * NT};
+    float2* s_xy = reinterpret_cast<float2*>(s_rw + 3 * NT + 16);
+    float4* s_co = reinterpret_cast<float4*>(s_rw + 3 * NT + 16 + 2 * NT);
+    uint32_t* s_gpre = s_rw + 3 * NT + 16 + 6 * NT;   // inclusive prefix of the Gaussians' row counts
+    uint32_t* s_grect = s_gpre + NT;         // clip columns x0 | x1 << 10, first row << 21
+    uint32_t* s_grad = s_grect + NT;         // radius (the margin of tau needs it)
+    uint32_t* s_q0 = s_grad + NT;            // EMIT, per span: upper band's columns lo | hi << 11, Gaussian slot << 22
+    uint32_t* s_q1 = s_q0 + NT;              //                 lower band's columns lo | hi << 11
     uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * ntiles_all + tile0;
     if (EMIT) {
-        for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
+        for (int t = tid; t < ntiles; t += NT) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
     } else {
-        for (int c = tid; c < (int)gy * stride; c += BIN_THREADS) s_grid[c] = 0;
+        for (int c = tid; c < (int)gy * stride; c += NT) s_grid[c] = 0;
     }
     __syncthreads();
     const int nwg = (int)gridDim.x;
-    const int rounds = ((P + 63) / 64 + 16 * nwg - 1) / (16 * nwg);
+    const int rounds = ((P + 63) / 64 + NW * nwg - 1) / (NW * nwg);   // 64-rank chunks dealt round robin over all waves of all workgroups
     // The record of the NEXT round is requested before this round's items are walked (a round is a chain of workgroup barriers
     // and LDS searches with one workgroup per CU: nothing else would hide the load).  Unconditional, index clamped: a
     // conditionally assigned load result is waited for on the spot.
     BlendRec nxt = rank_rec[min((wave * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
     for (int it = 0; it < rounds; it++) {
-        const int r = ((it * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
+        const int r = ((it * NW + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
         const BlendRec rec = nxt;
-        nxt = rank_rec[min((((it + 1) * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
+        nxt = rank_rec[min((((it + 1) * NW + wave) * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
         uint32_t h = 0;
         if (r < P) {
             const int rad = (int)rec.pm;
@@ -596,17 +590,17 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
             }
         }
         uint32_t rows_total;
-        s_gpre[tid] = workgroup_inclusive_scan(h, tid, rw.wsum, rows_total);
+        s_gpre[tid] = workgroup_inclusive_scan<NT>(h, tid, rw.wsum, rows_total);
         __syncthreads();
         if MI_ABLATE(1 << 20) rows_total = 0;
-        for (uint32_t w0 = 0; w0 < rows_total; w0 += 1024) {  // windows of 1024 (Gaussian, tile row) items
+        for (uint32_t w0 = 0; w0 < rows_total; w0 += NT) {  // windows of NT (Gaussian, tile row) items
             const uint32_t k = w0 + (uint32_t)tid;
             uint2 smin = make_uint2(0, 0), smax = make_uint2(0, 0);
             uint32_t width = 0;
             if (k < rows_total) {
                 int g = 0;  // first Gaussian slot with prefix > k
 #pragma unroll
-                for (int step = 512; step >= 1; step >>= 1)
+                for (int step = NT / 2; step >= 1; step >>= 1)
                     if (s_gpre[g + step - 1] <= k) g += step;
                 const uint32_t prev = g == 0 ? 0u : s_gpre[g - 1];
                 const uint32_t packed = s_grect[g];
@@ -643,7 +637,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
                 }
             }
             if (EMIT && !MI_ABLATE(1 << 16)) {
-                for_each_tile_balanced(
+                for_each_tile_balanced<NT>(
                     rw, tid, smin, smax, width,
                     [&](uint32_t owner, uint32_t tx, uint32_t ty) {
                         if MI_ABLATE(1 << 17) return;
@@ -654,7 +648,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
                                                ((uint32_t)(c - lo1 < n1) << 2) | ((uint32_t)(c + 1u - lo1 < n1) << 3);
                         if (qmask != 0u) {
                             const uint32_t slot_g = q0 >> 22;
-                            const uint32_t rank = (uint32_t)(((it * 16 + (int)(slot_g >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(slot_g & 63u));
+                            const uint32_t rank = (uint32_t)(((it * NW + (int)(slot_g >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(slot_g & 63u));
                             if MI_ABLATE(1 << 18) return;
                             const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
                             if MI_ABLATE(1 << 19) return;
@@ -668,7 +662,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_spans_kernel(int P, const Ble
     if (!EMIT) {
         __syncthreads();
         // prefix along x: one wave per row, 64 cells at a time with a carry -> the per-tile counts of this slice
-        for (int y = wave; y < (int)gy; y += BIN_THREADS / 64) {
+        for (int y = wave; y < (int)gy; y += NW) {
             int carry = 0;
             for (int x0 = 0; x0 < (int)gx; x0 += 64) {
                 const int x = x0 + lane;

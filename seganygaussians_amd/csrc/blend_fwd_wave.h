@@ -88,29 +88,18 @@ __device__ __forceinline__ void fwd_zero_fill(const FwdZeroFill& z, uint32_t wg,
     for (uint32_t i = wg * 64u + (uint32_t)lane; i < z.nb; i += nwg * 64u) z.b[i] = zero;
 }
 
-#ifndef MI_FWD_WAVES32
-#define MI_FWD_WAVES32 4   // waves per SIMD the 32-channel instance is compiled for (register budget 512 / waves)
-#endif
-#ifndef MI_FWD_WAVES64
-#define MI_FWD_WAVES64 3
-#endif
-// A/B switches of the 32/64-channel kernel's group loop (round 4):
-#ifndef MI_FWD_PF2
-#define MI_FWD_PF2 1          // 1 (product): the rows of a group are requested TWO groups ahead (two register sets) instead of one
-#endif
-#ifndef MI_FWD_LIVE_EVERY
-#define MI_FWD_LIVE_EVERY 1   // the wave-uniform "every pixel is done" test (a branch) in front of every k-th pair of entries; 8: none
-#endif
-#ifndef MI_FWD_SB
-#define MI_FWD_SB 1           // scheduling barrier behind every pair of entries
-#endif
+// Waves per SIMD the instances are compiled for (register budget 512 / waves): 32 channels 4 (five: spills, no gain), 64 channels 3.
+constexpr int FWD_WAVES32 = 4, FWD_WAVES64 = 3;
+// Measured and settled in round 4: the rows of a group are requested TWO groups ahead at 32 channels (two
+// register sets; at 64 channels the second set does not fit); the wave-uniform "every pixel is done" test sits in front of every
+// pair of entries; a scheduling barrier behind every pair keeps the record reads of later pairs from piling up in registers.
 
 // XM: how opacity * exp(power) is evaluated (common.h: ExpMode) -- EXP_HYBRID is the product default.
 // PARTIAL: only the first `cr_arg` (1 .. 31) of the block's 32 channels exist in memory -- the last channel block of a feature whose
 // width is no multiple of 32 (the reference compiles ANY NUM_CHANNELS, config_contrastive_f.h:15): feature rows are loaded channel by
 // channel with zeros behind cr (zeros in the MFMA operands, as RGB has always been blended), and only cr planes are written.
 template <int C, int XM = EXP_HYBRID, bool STRIDED = false, bool PARTIAL = false>
-__global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64) blend_fwd_wave_kernel(
+__global__ void __launch_bounds__(64, C == 32 ? FWD_WAVES32 : FWD_WAVES64) blend_fwd_wave_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
     int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ features, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_consumed /* zeroed: receives atomicMax */,
@@ -216,7 +205,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
     bool finished = false;
 
     // One group of up to 16 entries whose rows wait in `rr`; `n_ahead` rows of the group behind it are in flight in the other
-    // register set (MI_FWD_PF2) or none (n_ahead = 0).  Requests the group behind those into `rr` and returns its row count.
+    // register set (32 channels) or none (n_ahead = 0).  Requests the group behind those into `rr` and returns its row count.
     auto do_group = [&](RowRegs& rr, const int n, const int n_ahead) __attribute__((always_inline)) -> int {
         // ---- 1. the group's rows: registers -> LDS.  Rows beyond n (the wave's last group only) become padding: opacity 0
         // (never blends) and zero features.
@@ -278,10 +267,8 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
             uint64_t band = 0;
 #pragma unroll
             for (int i = 0; i < XG / 2; i++) {
-                // padding pair of the wave's last group, or every pixel is done (wave-uniform): w = 0.  MI_FWD_LIVE_EVERY > 1: the test
-                // (a branch: it cuts the group into basic blocks) only in front of every k-th pair -- a padding entry has opacity 0 and a
-                // finished pixel blends nothing, so an untested pair evaluates to w = 0 by itself
-                if ((MI_FWD_LIVE_EVERY == 1 && 2 * i >= n) || ((i % MI_FWD_LIVE_EVERY) == 0 && live == 0)) {
+                // padding pair of the wave's last group, or every pixel is done (wave-uniform): w = 0
+                if (2 * i >= n || live == 0) {
                     wp[0][i] = wp[1][i] = wp[2][i] = 0u;
                     continue;
                 }
@@ -317,9 +304,7 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
                     fin_j = (live == 0 && fin_j < 0) ? 2 * i + h : fin_j;  // first entry after which nobody is left
                 }
                 split3_bf16x2(w2[0], w2[1], wp[0][i], wp[1][i], wp[2][i]);
-#if MI_FWD_SB
                 __builtin_amdgcn_sched_barrier(0);  // keeps the record reads of later pairs from piling up in registers
-#endif
             }
             return band;
         };
@@ -396,11 +381,11 @@ __global__ void __launch_bounds__(64, C == 32 ? MI_FWD_WAVES32 : MI_FWD_WAVES64)
     int nA = min(XG, qt - qh);
     if (nA > 0) request_rows(setA, 0, nA);
     live = ballot64(!done);
-    // MI_FWD_PF2, 32 channels: rows requested TWO groups ahead -- a group of 16 entries takes a wave about as long as a dependent gather
+    // 32 channels: rows requested TWO groups ahead -- a group of 16 entries takes a wave about as long as a dependent gather
     // under load (~4 us), so one group of run-ahead leaves the wave waiting whenever the memory system is slower than its own
     // arithmetic (cfg3: 0.275 -> 0.268 ms).  At 64 channels the second register set (18 VGPRs) does not fit beside the accumulators
     // at three waves per SIMD (spills): one group ahead there.
-    constexpr bool PF2 = MI_FWD_PF2 != 0 && C == 32;
+    constexpr bool PF2 = C == 32;
     if constexpr (PF2) {
         int nB = 0;
         if (nA == XG) {

@@ -189,7 +189,7 @@ __device__ __forceinline__ float gauss_exp(float power)
 // and the gradient atomics of a Gaussian hit lines that L2 already holds instead of lines that travel between L2s -- backward
 // blend 0.647 -> 0.565 ms on cfg3.
 //   static:              workgroup id = 8 j + x is the j-th tile of XCD x's run.  The kernel time is then the busiest XCD's.
-//   dynamic (xcd_grab):  the backward blend's cost per tile is the scene's density, and a static split would hand one XCD the
+//   dynamic (xcd_grab_runs): the backward blend's cost per tile is the scene's density, and a static split would hand one XCD the
 //                        empty sky.  There the second half of every run is a QUEUE: a wave takes its item from the queue of
 //                        the XCD it runs on (one returning atomic on that XCD's counter; HW_REG_XCC_ID says which) and, when
 //                        that is empty, from the next XCD's.  As many such waves as queued items, each takes exactly one:
@@ -199,49 +199,16 @@ __device__ __forceinline__ float gauss_exp(float power)
 __host__ __device__ __forceinline__ uint32_t xcd_run_start(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * n) >> 3); }
 constexpr int XCD_QUEUE_STRIDE = 16;  // uint32 words between the eight queue counters (one 64-byte line each)
 constexpr uint32_t XCD_QUEUE_DIV = 2;  // the queued part of a run is its last 1 / XCD_QUEUE_DIV
-// The queued part of XCD x's run: its last len / XCD_QUEUE_DIV tiles.  xcd_static_len: the longest static part of any run.
-// (Half of the run: when half of the XCDs have nothing of their own to do -- a scene that fills half of the image -- the idle
-// half takes exactly the queued halves of the busy ones, and all finish together.  A quarter measured the same on cfg3.)
-__host__ __device__ inline uint32_t xcd_static_len(uint32_t n)
-{
-    const uint32_t longest = (n + 7u) >> 3;
-    return longest - longest / XCD_QUEUE_DIV;
-}
-__host__ __device__ inline uint32_t xcd_queued_tiles(uint32_t n)
-{
-    uint32_t q = 0;
-    for (uint32_t x = 0; x < 8u; x++) {
-        const uint32_t len = (uint32_t)(((uint64_t)(x + 1u) * n) >> 3) - (uint32_t)(((uint64_t)x * n) >> 3);
-        q += len / XCD_QUEUE_DIV;
-    }
-    return q;
-}
-// Takes one queued item (per items per tile, consecutive: e.g. the four quadrants); wave-uniform; 0xFFFFFFFF when every queue is
-// empty (cannot happen with exactly per * xcd_queued_tiles(n) takers).  counters: eight zeroed words, XCD_QUEUE_STRIDE apart.
-__device__ __forceinline__ uint32_t xcd_grab(uint32_t* __restrict__ counters, uint32_t n, uint32_t per)
-{
-    const uint32_t x0 = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
-    const bool first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;
-    for (uint32_t k = 0; k < 8u; k++) {
-        const uint32_t x = (x0 + k) & 7u;
-        const uint32_t start = xcd_run_start(x, n), len = xcd_run_start(x + 1u, n) - start;
-        uint32_t got = 0;
-        if (first) got = atomicAdd(&counters[x * XCD_QUEUE_STRIDE], 1u);
-        got = __builtin_amdgcn_readfirstlane(got);
-        if (got < (len / XCD_QUEUE_DIV) * per) return (start + len - len / XCD_QUEUE_DIV) * per + got;
-    }
-    return 0xFFFFFFFFu;
-}
-
-// WORK-balanced runs for the backward blend (round 5).  Equal tile counts per XCD are equal TIME only on a scene whose density does
-// not vary over the image: on the second synthetic law (opaque surfaces + floaters; real scenes are of this kind) the slowest XCD
-// ends 20-23 % behind the mean (profiles/r04_xcd_balance.md), and nothing lets a fast XCD take more -- the dispatcher hands
-// workgroup b to XCD b % 8 whatever the XCDs' progress.  What a tile costs the backward is what the forward WALKED of its list
-// (tile_nsurv; the list LENGTH is the wrong weight: an opaque surface ends a long list early), so a one-workgroup scan behind the
-// forward blend (binning.h: run_bounds_from_walks_kernel) cuts the row-major tile sequence into eight contiguous runs of equal
-// sum(tile_nsurv + XCD_TILE_WEIGHT) and leaves the nine boundaries in the image buffer; every forward's range scan writes the
-// equal-count boundaries there first, so the backward always finds valid ones.  A run holds at most XCD_MAX_RUN_FACTOR times the
-// equal share: that bounds the grid the (stateless) backward launches -- ids beyond a run's length exit at once.
+// WORK-balanced runs (round 5).  Equal tile counts per XCD are equal TIME only on a scene whose density does not vary over the image:
+// on the second synthetic law (opaque surfaces + floaters; real scenes are of this kind) the slowest XCD ended 20-23 % behind the
+// mean in both blend kernels (profiles/r04_xcd_balance.md), and nothing lets a fast XCD take more -- the dispatcher hands workgroup b
+// to XCD b % 8 whatever the XCDs' progress.  The range scan (binning.h: tile_ranges_kernel) therefore cuts the row-major tile
+// sequence into eight contiguous runs of equal MODELLED work, sum(min(list length, 768) + 128) -- the list LENGTH alone is the wrong
+// weight: an opaque surface ends a long list early --, and leaves the nine boundaries in the image buffer for both blend kernels
+// (profiles/r05_xcd_balance.md: cfg3s +7 %).  A knob (mi_rast.hip: BWD_RUNS_FROM_WALKS, off) replaces the backward's boundaries by
+// ones cut at equal sums of what the forward really WALKED (tile_nsurv + XCD_TILE_WEIGHT; run_bounds_from_walks_kernel, one more
+// launch behind the forward blend).  A run holds at most XCD_MAX_RUN_FACTOR times the equal share: that bounds the grid the
+// (stateless) backward launches -- ids beyond a run's length exit at once.
 constexpr uint32_t XCD_TILE_WEIGHT = 128;     // a tile's fixed cost (four waves' start-up) in list entries: 32 / 128 / 256 measured, round 4
 constexpr uint32_t XCD_MAX_RUN_FACTOR = 2;
 struct XcdRuns {
