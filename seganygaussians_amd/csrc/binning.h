@@ -493,10 +493,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
 // LDS words of the hand-off arrays of a workgroup of nt threads: RectWork + means + conics + prefix / rect / radius / two bands' columns
 __host__ __device__ constexpr int span_lds_words(int nt) { return (3 * nt + 16) + 2 * nt + 4 * nt + 5 * nt; }
 constexpr int SPAN_LDS_WORDS = span_lds_words(1024);
-// Threads per workgroup of the LEAN count / emit passes.  512: two workgroups share a CU (2 x 61 KB of LDS at 1080p) and overlap each
-// other's workgroup-barrier phases -- the passes are chains of such phases at ~1 us each --, at the price of twice
-// as many rank slices (the partial[][] table and its scan double).  Measured in round 5: profiles/r05_front_half.md.
-constexpr int BIN_LEAN_THREADS = 512;
+// Threads per workgroup of the LEAN count / emit passes.  512 (profiling build, MI_RAST_BIN_NT): two workgroups share a CU (2 x 61 KB of
+// LDS at 1080p) and overlap each other's workgroup-barrier phases, at the price of twice as many rank slices.  Measured in round 5
+// (profiles/r05_front_half.md): emit 0.071 -> 0.065 ms, but count + scans 0.057 -> 0.068 (the partial[][] table and its scan double):
+// 1024 stays.
+constexpr int BIN_LEAN_THREADS = 1024;
 constexpr int BIN_LEAN_MAX_WG = 512;
 inline int bin_lean_workgroups(int P, int nt)
 {

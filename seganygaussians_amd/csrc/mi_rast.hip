@@ -438,8 +438,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef MI_RAST_PROFILING
             HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)run_bounds_from_walks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -487,7 +489,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     const bool full = debug != 0 || nocull || (flags & MI_RAST_FULL_LISTS) != 0;
     // full lists: <= 256 workgroups of 1024 threads; lean lists: workgroups of BIN_LEAN_THREADS (binning.h; MI_RAST_BIN_NT in the
     // profiling build), twice as many slices when they are 512 threads wide
+#ifdef MI_RAST_PROFILING
     const int lean_nt = knob("MI_RAST_BIN_NT", BIN_LEAN_THREADS) == 512 ? 512 : 1024;
+#else
+    constexpr int lean_nt = BIN_LEAN_THREADS;
+#endif
     int nwg = full ? bin_workgroups(P) : bin_lean_workgroups(P, lean_nt);
 #ifdef MI_RAST_PROFILING
     if (ablate_env("MI_RAST_NWG") > 0) nwg = std::min(nwg, ablate_env("MI_RAST_NWG"));
@@ -503,11 +509,13 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             if (full)
                 hipLaunchKernelGGL(bin_count_kernel, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
                                    img.tile_count, vp.grid_x, vp.grid_y, by0, by1);
+#ifdef MI_RAST_PROFILING
             else if (lean_nt == 512)
                 hipLaunchKernelGGL((bin_spans_kernel<false, 512>), dim3(nwg), dim3(512),
                                    ((((size_t)(by1 - by0) * count_grid_stride(vp.grid_x) + 3) & ~(size_t)3) + span_lds_words(512)) * sizeof(uint32_t),
                                    stream, P, geom.rank_rec, img.tile_count, (const uint2*)nullptr, (uint32_t*)nullptr, vp.grid_x,
                                    vp.grid_y, by0, by1, g_ablate_fwd);
+#endif
             else
                 hipLaunchKernelGGL((bin_spans_kernel<false, 1024>), dim3(nwg), dim3(1024),
                                    ((((size_t)(by1 - by0) * count_grid_stride(vp.grid_x) + 3) & ~(size_t)3) + span_lds_words(1024)) * sizeof(uint32_t),
@@ -556,10 +564,12 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                 else if (full)
                     hipLaunchKernelGGL(bin_ranks_kernel<false>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
+#ifdef MI_RAST_PROFILING
                 else if (lean_nt == 512)
                     hipLaunchKernelGGL((bin_spans_kernel<true, 512>), dim3(nwg), dim3(512),
                                        ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + span_lds_words(512)) * sizeof(uint32_t), stream, P,
                                        geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1, g_ablate_fwd);
+#endif
                 else
                     hipLaunchKernelGGL((bin_spans_kernel<true, 1024>), dim3(nwg), dim3(1024),
                                        ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + span_lds_words(1024)) * sizeof(uint32_t), stream, P,
@@ -992,7 +1002,12 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     off[MI_IMG_RANGES] = c.take((tiles ? tiles : 1) * sizeof(uint2));
     off[MI_IMG_TILE_CONSUMED] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     // tile_count holds partial[slice][tile] of the count / emit passes (binning.h); tile_cursor the tile totals
-    off[MI_IMG_TILE_COUNT] = c.take((size_t)BIN_LEAN_MAX_WG * (tiles ? tiles : 1) * sizeof(uint32_t));
+#ifdef MI_RAST_PROFILING
+    constexpr int max_slices = BIN_LEAN_MAX_WG;   // (MI_RAST_BIN_NT=512: twice the rank slices)
+#else
+    constexpr int max_slices = BIN_MAX_WG;
+#endif
+    off[MI_IMG_TILE_COUNT] = c.take((size_t)max_slices * (tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_NUM_RENDERED] = c.take((R_SLOTS * R_SLOT_STRIDE + 16) * sizeof(int));  // R partial sums, then {R, longest list}, then the nine run boundaries
     off[MI_IMG_TILE_NSURV] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
