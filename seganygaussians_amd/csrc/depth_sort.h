@@ -24,7 +24,8 @@ namespace mirast {
 constexpr int DS_NB = 16384;
 constexpr int DS_NBK = DS_NB + 1;  // + the bucket of culled Gaussians
 constexpr int DS_MAX_WG = 128;  // measured 16 / 32 / 64 / 128 / 192 / 256 slices on cfg3: depth order 0.122 / 0.092 / 0.078 / 0.074 / 0.076 / 0.077 ms
-constexpr int DS_WAVE = 256;     // pairs per bucket ranked by ONE wave (four buckets per workgroup, no barriers)
+constexpr int DS_WAVE = 512;     // pairs per bucket ordered by ONE wave (four buckets per workgroup, no barriers)
+constexpr int DS_WAVE_COUNT = 128;  // ... by counting up to this many pairs, by a bitonic network in LDS above
 constexpr int DS_COUNTING = 512;  // buckets up to this size are ranked by counting instead of radix passes
 constexpr int DS_LARGE = 2048;   // pairs per bucket the second kernel holds in LDS (36 KB: four workgroups per CU)
 
@@ -193,52 +194,86 @@ __device__ __forceinline__ void radix_pass_pairs(Src src, Dst dst, int n, int sh
     __syncthreads();
 }
 
-// Buckets of up to DS_WAVE pairs (the common case: ~100 pairs on a 1 M-Gaussian view): one WAVE per bucket ranks its
-// pairs by counting -- every pair is compared with every other one through LDS broadcast reads; (key, index) pairs
-// are distinct, so the ranks are a permutation -- and scatters sorted_idx / the 32-byte records by rank.
+// Buckets of up to DS_WAVE pairs: one WAVE per bucket, four buckets per workgroup, no workgroup barriers.
+//   * up to DS_WAVE_COUNT pairs (the common case: ~100 pairs on a 1 M-Gaussian view): ranking by counting -- every pair is compared
+//     with every other one through LDS broadcast reads; (key, index) pairs are distinct, so the ranks are a permutation;
+//   * above (the common case of a 5 M-Gaussian view: ~300 pairs per bucket, where counting is O(n^2): 0.17 of cfg5's 0.33-ms depth
+//     order until round 5): a bitonic network over the pairs padded to 256 / 512 in LDS, wave-synchronous -- log^2 steps of n / 2
+//     compare-exchanges instead of n^2 comparisons.
+// Either way the wave then scatters sorted_idx / the 32-byte records by rank.
 __global__ void __launch_bounds__(256) depth_bucket_sort_wave_kernel(const uint2* __restrict__ ranges,
                                                                      const uint2* __restrict__ pairs,
                                                                      const BlendRec* __restrict__ index_rec,
                                                                      uint32_t* __restrict__ sorted_idx,
                                                                      BlendRec* __restrict__ rank_rec)
 {
-    __shared__ uint32_t s_k[4][DS_WAVE];
-    __shared__ uint32_t s_v[4][DS_WAVE];
+    __shared__ uint64_t s_p[4][DS_WAVE];   // (key << 32 | index) of the wave's bucket
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if (b >= DS_NB) return;
     const uint2 range = ranges[b];
     const int n = (int)(range.y - range.x);
     if (n == 0 || n > DS_WAVE) return;  // longer buckets are on the big-bucket list
-    constexpr int EPL = DS_WAVE / 64;   // elements per lane
-    uint64_t mine[EPL];
+    uint64_t* const sp = s_p[wave];
+    if (n <= DS_WAVE_COUNT) {
+        constexpr int EPL = DS_WAVE_COUNT / 64;   // elements per lane
+        uint64_t mine[EPL];
 #pragma unroll
-    for (int t = 0; t < EPL; t++) {
-        const int e = lane + 64 * t;
-        uint2 p = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (e < n) {
-            p = pairs[range.x + e];
-            s_k[wave][e] = p.x;
-            s_v[wave][e] = p.y;
+        for (int t = 0; t < EPL; t++) {
+            const int e = lane + 64 * t;
+            uint2 p = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (e < n) p = pairs[range.x + e];
+            mine[t] = ((uint64_t)p.x << 32) | p.y;
+            if (e < n) sp[e] = mine[t];
         }
-        mine[t] = ((uint64_t)p.x << 32) | p.y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        int rank[EPL];
+#pragma unroll
+        for (int t = 0; t < EPL; t++) rank[t] = 0;
+        for (int q = 0; q < n; q++) {
+            const uint64_t other = sp[q];
+#pragma unroll
+            for (int t = 0; t < EPL; t++) rank[t] += other < mine[t] ? 1 : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < EPL; t++) {
+            if (lane + 64 * t < n) {
+                const uint32_t g = (uint32_t)mine[t];
+                rank_rec[range.x + rank[t]] = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
+                sorted_idx[range.x + rank[t]] = g;
+            }
+        }
+        return;
+    }
+    // bitonic network over m = 256 or 512 slots (padding: the largest word, which ends up behind every pair)
+    const int m = n <= 256 ? 256 : 512;
+    for (int e = lane; e < m; e += 64) {
+        uint64_t w = 0xFFFFFFFFFFFFFFFFull;
+        if (e < n) {
+            const uint2 p = pairs[range.x + e];
+            w = ((uint64_t)p.x << 32) | p.y;
+        }
+        sp[e] = w;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    int rank[EPL];
-#pragma unroll
-    for (int t = 0; t < EPL; t++) rank[t] = 0;
-    for (int q = 0; q < n; q++) {
-        const uint64_t other = ((uint64_t)s_k[wave][q] << 32) | s_v[wave][q];
-#pragma unroll
-        for (int t = 0; t < EPL; t++) rank[t] += other < mine[t] ? 1 : 0;
-    }
-#pragma unroll
-    for (int t = 0; t < EPL; t++) {
-        if (lane + 64 * t < n) {
-            const uint32_t g = (uint32_t)mine[t];
-            rank_rec[range.x + rank[t]] = index_rec[g];  // one 32-byte gather: {mean, id, radius, conic + opacity}
-            sorted_idx[range.x + rank[t]] = g;
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (m >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // the t-th index whose bit j is clear; its partner is i + j
+                const uint64_t a = sp[i], c = sp[i + j];
+                const bool up = (i & k) == 0;                          // ascending block
+                if ((a > c) == up) {
+                    sp[i] = c;
+                    sp[i + j] = a;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the compare-exchanges of one step touch disjoint pairs)
         }
+    }
+    for (int e = lane; e < n; e += 64) {
+        const uint32_t g = (uint32_t)sp[e];
+        rank_rec[range.x + e] = index_rec[g];
+        sorted_idx[range.x + e] = g;
     }
 }
 
