@@ -596,7 +596,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
 #endif
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
-            // four list-length classes (256 threads + 20 KB of LDS, 512 + 40 KB, 1024 + 64 KB, 1024 + 112 KB); a class is launched only if
+            // three list-length classes (256 threads + 20 KB of LDS, 1024 threads + 64 KB, 1024 threads + 112 KB); a class is launched only if
             // some tile needs it.  The longest list was copied to the host right after the range scan, which
             // finished before the emit pass above even started: this wait does not stall the queue.
 #define LAUNCH_TILE_SORT(LO, CAP, FB, NT)                                                                                 \
@@ -609,10 +609,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             if (full ? g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R : g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] > R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
-            // (2048, 4064]: 512 threads + 40 KB of LDS -- four workgroups per CU instead of the two a 1024-thread / 64-KB class gets: the
-            // sort is a chain of workgroup-barrier phases, concurrency is what shortens it (cfg5: lists of ~3000 entries)
-            if (max_tile_count > 2048) LAUNCH_TILE_SORT(2048, 4064, false, 512);   // (4064: four workgroups x 40.7 KB fit the 160 KB of a CU)
-            if (max_tile_count > 4064) LAUNCH_TILE_SORT(4064, 6144, false, 1024);
+            if (max_tile_count > 2048) LAUNCH_TILE_SORT(2048, 6144, false, 1024);
             if (max_tile_count > 6144) LAUNCH_TILE_SORT(6144, 12288, true, 1024);
 #undef LAUNCH_TILE_SORT
         }
