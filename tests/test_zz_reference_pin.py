@@ -214,9 +214,9 @@ def test_product_vs_ref_channel_blocks(C):
 # oracle in round 3: cov3D 8.1e-6 .. 8.2e-5, scales 1.2e-5 .. 6.7e-5, rotations 3.3e-5 .. 1.3e-4).  These three are therefore
 # judged on DRAWS taken inside the test -- the backward of the reference and of the product each run SWING_DRAWS times on the
 # same forward -- and on the TRIMMED norm-wise error (helpers.trimmed_norm_error: the 32 worst rows of either side left out of
-# the numerator): the product's MEDIAN must stay within 2x the reference's LARGEST.  The untrimmed norm keeps a gross bound (8x
-# the reference's largest draw), and the rows left out are still counted by the rows-outside-tolerance share (2x the
-# reference's).  Round 3 bounded the three by constants copied from earlier runs instead.  Every other tensor is stable (measured
+# the numerator), compared like with like: the product's MEDIAN within 2x the reference's MEDIAN and its LARGEST draw within 2x the
+# reference's largest.  The untrimmed norm keeps a gross bound (8x the reference's largest draw), and the rows left out are still
+# counted by the rows-outside-tolerance share (2x the reference's).  Round 3 bounded the three by constants copied from earlier runs instead.  Every other tensor is stable (measured
 # ratios 0.9 .. 1.1) and keeps the 4x-of-this-run bound on the plain norm.
 SWING = ("dL_dcov3D", "dL_dscales", "dL_drotations")
 SWING_DRAWS = 3
@@ -227,7 +227,7 @@ def _norm_bound(k, ref_norm, factor=4.0):
 
 
 def _swing_draws(gpu, ref, dL, dLm, ob, mine, theirs):
-    """{tensor: {statistic: (product's median, reference's max)}} of the (trimmed) norm-wise error against `ob` over SWING_DRAWS
+    """{tensor: {statistic: (product's median, reference's max, product's max, reference's median)}} of the (trimmed) norm-wise error against `ob` over SWING_DRAWS
     backward runs each (the draws already in `mine` / `theirs` count as the first)."""
     stats = ("norm_trim", "norm")
     prod = {k: {st: [mine[k][st]] for st in stats} for k in SWING if k in mine}
@@ -239,7 +239,8 @@ def _swing_draws(gpu, ref, dL, dLm, ob, mine, theirs):
             for st in stats:
                 prod[k][st].append(g[k][st])
                 refd[k][st].append(r[k][st])
-    return {k: {st: (float(np.median(prod[k][st])), float(max(refd[k][st]))) for st in stats} for k in prod}
+    return {k: {st: (float(np.median(prod[k][st])), float(max(refd[k][st])), float(max(prod[k][st])), float(np.median(refd[k][st])))
+                for st in stats} for k in prod}
 
 
 def _judge_against_reference(what, mine, theirs, swing):
@@ -250,10 +251,13 @@ def _judge_against_reference(what, mine, theirs, swing):
               f" | reference's own: norm {r['norm']:.2e} (trimmed {r['norm_trim']:.2e}) rows {r['row_frac']:.2e} worst {r['row_worst']:.1f}")
         assert not s["zero_rows_touched"]
         if k in swing:
-            (med_t, ref_t), (med, ref_max) = swing[k]["norm_trim"], swing[k]["norm"]
-            print(f"{what} {k}: over {SWING_DRAWS} draws each, trimmed norm: product median {med_t:.2e}, reference max {ref_t:.2e}; "
-                  f"plain norm: product median {med:.2e}, reference max {ref_max:.2e}")
-            norm_ok = med_t <= 2 * ref_t + 1e-7 and med <= 8 * ref_max + 1e-7
+            (med_t, ref_t, max_t, ref_med_t), (med, ref_max, _, _) = swing[k]["norm_trim"], swing[k]["norm"]
+            print(f"{what} {k}: over {SWING_DRAWS} draws each, trimmed norm: product median {med_t:.2e} / max {max_t:.2e}, reference median "
+                  f"{ref_med_t:.2e} / max {ref_t:.2e}; plain norm: product median {med:.2e}, reference max {ref_max:.2e}")
+            # the trimmed norm is the stable statistic (round 5, five full runs: product / reference between 0.8 and 1.1 on every case): it is
+            # compared like with like -- median with median, largest draw with largest draw; the plain norm, which one row carries and which
+            # swings tenfold between draws of either side, keeps its gross bound
+            norm_ok = med_t <= 2 * ref_med_t + 1e-7 and max_t <= 2 * ref_t + 1e-7 and med <= 8 * ref_max + 1e-7
         else:
             norm_ok = s["norm"] <= _norm_bound(k, r["norm"])
         if not (norm_ok and s["row_frac"] <= 2 * r["row_frac"] + 5e-5):
