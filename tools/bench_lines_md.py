@@ -8,7 +8,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"lines_{tag}")
 runs = [("cfg3_default", "python bench.py"), ("cfg3", "python bench.py --ref-on-gpu --steps 30"), ("cfg2", "python bench.py --config cfg2"),
         ("cfg3s", "python bench.py --config cfg3s"), ("cfg5", "python bench.py --config cfg5 --ref-on-gpu"), ("cfg1", "python bench.py --config cfg1"),
-        ("dist", "python bench.py --dist-single --steps 10 --warmup 3"), ("fastexp", "python bench.py --fast-exp --no-cpu-baseline")]
+        ("dist", "python bench.py --dist-single --steps 10 --warmup 3"), ("dist_rsag", "python bench.py --dist-single --rs-ag --steps 10 --warmup 3"), ("fastexp", "python bench.py --fast-exp --no-cpu-baseline")]
 out = [f"# Bench lines of the final round build ({tag})",
        "`python bench.py [--config ...]` on 1x MI355X through gpurun (default: 100 timed steps after 10 warm-up steps and the settling blocks); "
        "`--ref-on-gpu` adds `reference_on_gpu` (oracle/_ref = the reference's own kernels, hipify-perl at build time, timed on the same workload "

@@ -9,4 +9,5 @@ python bench.py --config cfg3s > $OUT/cfg3s.log 2>&1
 python bench.py --config cfg5 --ref-on-gpu > $OUT/cfg5.log 2>&1
 python bench.py --config cfg1 > $OUT/cfg1.log 2>&1
 python bench.py --dist-single --steps 10 --warmup 3 > $OUT/dist.log 2>&1
+python bench.py --dist-single --rs-ag --steps 10 --warmup 3 > $OUT/dist_rsag.log 2>&1
 [ -n "$WITH_FASTEXP" ] && python bench.py --fast-exp --no-cpu-baseline > $OUT/fastexp.log 2>&1
