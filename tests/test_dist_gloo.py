@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from seganygaussians_amd import scenes
-from seganygaussians_amd.dist import (ViewShardedStep, allreduce_grads, allreduce_grads_async, shard_range, sharded_update_async,
+from seganygaussians_amd.dist import (ShardedAdam, ViewShardedStep, allreduce_grads, allreduce_grads_async, shard_range, sharded_update_async,
                                       views_for_rank)
 
 NUM_VIEWS, P, W, H, C = 5, 400, 64, 48, 32
@@ -94,6 +94,20 @@ def _worker(rank, world, port, out_dir):
                 want.add_(m, alpha=-0.1)
             assert len(touched) == 2 and torch.allclose(param.view(-1), want, rtol=1e-6, atol=1e-6), shape
             np.save(os.path.join(out_dir, f"sharded_{shape[0]}_{rank}.npy"), param.numpy())
+        # ShardedAdam (moments for this rank's rows only) against torch.optim.Adam on the whole tensor with the summed gradients
+        g0 = torch.Generator().manual_seed(23)
+        p0 = torch.randn((P, C), generator=g0)
+        steps = [[torch.randn((P, C), generator=g0) * 1e-3 for _ in range(world)] for _ in range(3)]
+        mine_p, opt = p0.clone(), ShardedAdam(lr=0.0025)
+        ref_p = torch.nn.Parameter(p0.clone())
+        ref_opt = torch.optim.Adam([ref_p], lr=0.0025)
+        for gs in steps:
+            sharded_update_async(mine_p, gs[rank].clone(), opt)
+            ref_p.grad = sum(gs)
+            ref_opt.step()
+        lo, hi = shard_range(p0.numel(), rank, world)
+        assert opt.exp_avg.numel() == hi - lo and opt.step == 3
+        assert torch.allclose(mine_p, ref_p.detach(), rtol=1e-5, atol=1e-7), float((mine_p - ref_p.detach()).abs().max())
     finally:
         dist.destroy_process_group()
 
