@@ -6,18 +6,25 @@
 // find per-tile ranges.  The RESULT -- point_list ordered by (tile, depth bits, Gaussian index) and
 // ranges[tile] -- is part of the bit-exact integer contract; the way to get there is not.
 //
-// MI355X design (produces the identical point_list / ranges):
-//   1. the per-Gaussian preprocess kernel sums tiles_touched into R (what the host needs to size the binning buffer);
-//   2. ONE 32-bit radix sort of the P Gaussians by depth bits (stable, so ties keep index order) turns
-//      every visible Gaussian into a dense RANK in [0,V): ordering by rank == ordering by (depth, index);
-//   3. a count pass over rank slices (per-tile counters in LDS), a scan over (tile, slice), and the scan of the tile
-//      totals give ranges[tile] and every slice's base inside every tile -- no global atomics;
-//   4. rank emission: each (Gaussian, tile) overlap takes its slot from an LDS cursor and stores the 4-byte RANK
-//      (arrival order inside a tile is arbitrary within a slice);
-//   5. per-tile LDS radix sort of the ranks (<= 24 significant bits, 8-bit digits, stable wave-match
-//      ranking), then blend_list[slot] = sorted_idx[rank] | quadrant mask << 28 (full lists: the low 28 bits are point_list).
-// HBM traffic per overlap drops from ~172 B to ~16 B (4 B emit write, 4 B sort read, 4 B list
-// write, 4 B L2-resident gather); the 64-bit keys are never materialised.
+// MI355X design (produces the identical point_list / ranges), five launches behind the preprocess pass:
+//   1. the per-Gaussian preprocess kernel sums tiles_touched into R (what the host needs to size the binning buffer) and
+//      leaves one 32-byte record {mean, id, radius, conic, opacity} and the depth bits of every visible Gaussian;
+//   2. a count pass over slices of the Gaussians IN INDEX ORDER (per-tile counters in LDS), a scan over (tile, slice),
+//      and the scan of the tile totals give ranges[tile] and every slice's base inside every tile -- no global atomics;
+//   3. emission: each (Gaussian, tile) overlap takes its slot from an LDS cursor and stores the 8-byte entry
+//      {depth bits, Gaussian id | quadrant mask << 28} (arrival order inside a tile is arbitrary);
+//   4. per-tile LDS radix sort of the entries by their depth bits (only the bits in which the view's keys differ:
+//      3-4 passes of 8 bits), entries of EQUAL depth ordered by id behind it, then blend_list[slot] = id | mask << 28
+//      (full lists: the low 28 bits are point_list).
+// Rounds 1-5 ordered the P Gaussians by depth first (six launches, 0.08 ms on a 1 M-Gaussian view) so that a tile's
+// entries were 20-bit ranks; round 6 drops that stage: the per-tile sort has the depth bits themselves as its key, one
+// radix pass more for six launches and 120 MB of traffic less.  The count / emit passes are wave-granular: a wave owns
+// 64 consecutive Gaussians, walks their (Gaussian, tile row) items and the tiles of their spans with wave-synchronous LDS
+// hand-offs, and meets the other waves of its workgroup only in the shared per-tile counters (LDS atomics) -- no workgroup
+// barrier inside the loop (a barrier phase of a 1024-thread workgroup costs about 1 us on this part, and rounds 2-5 paid
+// ~50 of them per workgroup).
+// HBM traffic per overlap drops from ~172 B to ~24 B (8 B emit write, 8 B sort read, 4 B list write, 4 B blend scan);
+// the 64-bit keys are never materialised.
 #pragma once
 
 #include "common.h"
@@ -25,12 +32,6 @@
 
 namespace mirast {
 
-// ---- workgroup-balanced enumeration of tile rects -------------------------------------------------------
-// Each of the 1024 threads owns one Gaussian with `count` tiles (0 if culled) in rect [rmin, rmax).  Tile counts
-// are extremely skewed along the depth-rank axis (BASELINE cfg3: median 6 tiles, 99.9th percentile 484, maximum
-// 4056; the heaviest 64 consecutive ranks hold 12x the average), so the WORKGROUP walks the concatenation of all
-// 1024 rects with every thread busy: item k belongs to the thread whose inclusive prefix first exceeds k (binary
-// search in an LDS copy of the prefix), and its tile follows from k's offset inside that rect.
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
 {
 #pragma unroll
@@ -42,7 +43,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
 }
 
 // Row of partial[][] (= position of the slice inside every tile's segment) of workgroup b.  Workgroup b runs on XCD b % 8
-// (tools/xcc_probe.hip) and each XCD has its own L2: with the slices of one XCD next to each other, the 4-byte entries that
+// (tools/xcc_probe.hip) and each XCD has its own L2: with the slices of one XCD next to each other, the entries that
 // share a 128-byte line of a tile's segment are mostly stored from ONE XCD instead of eight (measured: emit 0.086 -> 0.074 ms;
 // the HBM write bytes of the pass did not change).  Any bijection is correct -- count, scan and emit only have to agree on it.
 __device__ __forceinline__ uint32_t slice_row(uint32_t b, uint32_t nwg)
@@ -50,6 +51,11 @@ __device__ __forceinline__ uint32_t slice_row(uint32_t b, uint32_t nwg)
     return (nwg & 7u) ? b : (b & 7u) * (nwg >> 3) + (b >> 3);
 }
 
+// ---- workgroup-balanced enumeration of tile rects (full lists only: parity tests, the reference's `debug` flag) ----------
+// Each of the 1024 threads owns one Gaussian with `count` tiles (0 if culled) in rect [rmin, rmax).  Tile counts
+// are extremely skewed (BASELINE cfg3: median 6 tiles, 99.9th percentile 484, maximum 4056), so the WORKGROUP walks the
+// concatenation of all 1024 rects with every thread busy: item k belongs to the thread whose inclusive prefix first
+// exceeds k (binary search in an LDS copy of the prefix), and its tile follows from k's offset inside that rect.
 struct RectWork {
     uint32_t* prefix;  // LDS [NT] inclusive prefix of counts
     uint32_t* rx;      // LDS [NT] rect_min.x | width << 16
@@ -57,8 +63,7 @@ struct RectWork {
     uint32_t* wsum;    // LDS [16]
 };
 
-// Contains workgroup barriers: call from all NT threads (NT = 1024, or 512: two workgroups per CU).  f(owner_thread, tile_x, tile_y)
-// handles one item.
+// Contains workgroup barriers: call from all NT threads.  f(owner_thread, tile_x, tile_y) handles one item.
 template <int NT = 1024, typename F>
 __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int tid, uint2 rmin, uint2 rmax, uint32_t count, F&& f)
 {
@@ -97,30 +102,30 @@ __device__ __forceinline__ void for_each_tile_balanced(const RectWork& rw, int t
     __syncthreads();  // LDS hand-off arrays are reused by the next call
 }
 
-// ---- 3. tile ranges: exclusive scan of the per-tile totals (single workgroup) ------------------------------
+// ---- tile ranges: exclusive scan of the per-tile totals (single workgroup) ---------------------------------
 // Writes ranges[tile] = [base, base+count) (== identifyTileRanges' result, rasterizer_impl.cu:116-138, including
 // {0,0} for empty tiles as left by the reference's cudaMemset), R and the longest list.
-constexpr int RANK_BITS = 28;          // entry = depth rank | quadrant mask << 28
-constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
-constexpr int BIN_MAX_WG = 256;        // workgroups of the count / emit passes (rank slices): one per CU, all resident at once
-                                       // (measured 512 / 256 / 128 / 64 slices on cfg3: count + emit 0.167 / 0.146 / 0.199 / 0.349 ms)
+constexpr int ID_BITS = 28;            // list entry = Gaussian id | quadrant mask << 28
+constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
+constexpr int BIN_MAX_WG = 256;        // workgroups of the count / emit passes (slices of the Gaussians): one per CU, all resident at once
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_TILES = 26 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 57 KB of hand-off
+constexpr int BIN_MAX_TILES = 22 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 61 KB of hand-off
                                                // arrays must fit in 160 KB; larger images are walked in bands of tile rows
 constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
 
+// Words behind the R partial sums of the image buffer's num_rendered field (mi_rast.hip: ImgPtrs)
+constexpr int NR_TOTAL = 0, NR_LONGEST = 1, NR_VERIFY = 2, NR_KEY_BITS = 3, NR_RUN_BOUNDS = 4;
+
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const uint32_t* __restrict__ tile_total,
                                                            uint2* __restrict__ ranges, int* __restrict__ num_rendered,
-                                                           uint32_t big_threshold, int big_limit,
-                                                           uint32_t* __restrict__ big_list, int* __restrict__ host_out = nullptr,
+                                                           const int* __restrict__ r_slots, int* __restrict__ host_out = nullptr,
                                                            uint32_t* __restrict__ zero_a = nullptr, uint32_t* __restrict__ zero_b = nullptr,
                                                            uint32_t* __restrict__ run_bounds = nullptr /* [9]: the blend kernels' XCD runs
                                                                (common.h): equal tile counts, or equal MODELLED work when run_cap > 0 */,
                                                            uint32_t run_cap = 0, uint32_t run_fix = 0)
 {
     // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
-    // one workgroup scan joins the pieces, and the ranges leave coalesced again.  Items below big_limit with more
-    // than big_threshold entries are appended to big_list (count in big_list[0], order arbitrary).
+    // one workgroup scan joins the pieces, and the ranges leave coalesced again.
     // More than BIN_MAX_TILES_TOTAL items (images beyond 10 Mpx) are walked in segments of that many, one after the other, the
     // running total carried along: ONE pass of the loop below for every image up to 4096 x 2544.
     // run_cap > 0 (images of one segment): the XCD runs of the blend kernels are cut at equal sums of the
@@ -128,18 +133,28 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
     // run_cap entries where the scene is dense, and to its end where it is sparse; what a walk really covers is only known behind the
     // forward blend (run_bounds_from_walks_kernel) -- the second prefix sum rides on the first, at the granularity of the threads'
     // pieces (registers only); the thread whose piece holds a boundary walks its few tiles.
+    // Also left for the per-tile sort: the number of low key bits in which the view's depth keys differ at all (NR_KEY_BITS) --
+    // min and max key share every bit above, and so does every key between them.
     extern __shared__ uint32_t s_val[];  // [min(ntiles_all, BIN_MAX_TILES_TOTAL) + 1]
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_wave_w[16];
     __shared__ uint32_t s_bound[9];
     const bool weighted = run_bounds != nullptr && run_cap > 0u && ntiles_all <= BIN_MAX_TILES_TOTAL;   // (one segment)
     __shared__ uint32_t s_maxcount;
-    __shared__ uint32_t s_nbig;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 9) s_bound[tid] = xcd_run_start((uint32_t)tid, (uint32_t)ntiles_all);   // equal tile counts unless the model says otherwise
-    if (tid == 0) {
-        s_maxcount = 0;
-        s_nbig = 0;
+    if (tid == 0) s_maxcount = 0;
+    if (wave == 15 && r_slots != nullptr) {   // (a wave that has the least to do below)
+        uint32_t inv_min = (uint32_t)r_slots[(lane % R_SLOTS) * R_SLOT_STRIDE + 1];
+        uint32_t mx = (uint32_t)r_slots[(lane % R_SLOTS) * R_SLOT_STRIDE + 2];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            inv_min = max(inv_min, (uint32_t)__shfl_xor((int)inv_min, o, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        }
+        const uint32_t kmin = ~inv_min;   // no visible Gaussian: kmin = 0xFFFFFFFF > mx = 0
+        const uint32_t diff = mx >= kmin ? (mx ^ kmin) : 0u;
+        if (lane == 0) num_rendered[NR_KEY_BITS] = diff ? 32 - __builtin_clz(diff) : 0;
     }
     uint32_t carry = 0;   // entries in front of the segment (the same in every thread)
     for (int seg0 = 0; seg0 < ntiles_all; seg0 += BIN_MAX_TILES_TOTAL) {
@@ -212,8 +227,6 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
                 zero_a[seg0 + i] = 0u;
                 zero_b[seg0 + i] = 0u;
             }
-            if (big_list != nullptr && seg0 + i < big_limit && hi - lo > big_threshold)
-                big_list[1 + atomicAdd(&s_nbig, 1u)] = (uint32_t)(seg0 + i);
         }
         carry += total;
         __syncthreads();   // s_val / s_wave are rewritten by the next segment
@@ -235,18 +248,17 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
 #pragma unroll
             for (int k = 0; k < 9; k++) {
                 run_bounds[k] = bb[k];
-                if (host_out != nullptr) host_out[4 + k] = (int)bb[k];   // the forward's grid is sized for its longest run
+                if (host_out != nullptr) host_out[NR_RUN_BOUNDS + k] = (int)bb[k];   // the forward's grid is sized for its longest run
             }
         }
     }
     if (tid == 0) {
-        num_rendered[0] = (int)carry;       // R (the host already has it from the preprocess pass; kept for checks)
-        num_rendered[1] = (int)s_maxcount;  // longest list
-        if (host_out != nullptr) {          // the same two words straight into the host's pinned buffer (no copy command)
-            host_out[0] = (int)carry;
-            host_out[1] = (int)s_maxcount;
+        num_rendered[NR_TOTAL] = (int)carry;         // R (the host already has it from the preprocess pass; kept for checks)
+        num_rendered[NR_LONGEST] = (int)s_maxcount;  // longest list
+        if (host_out != nullptr) {                   // the same two words straight into the host's pinned buffer (no copy command)
+            host_out[NR_TOTAL] = (int)carry;
+            host_out[NR_LONGEST] = (int)s_maxcount;
         }
-        if (big_list != nullptr) big_list[0] = s_nbig;
     }
 }
 
@@ -305,8 +317,9 @@ __global__ void __launch_bounds__(1024) run_bounds_from_walks_kernel(int ntiles,
 }
 
 // Everything needed to evaluate a Gaussian at a pixel in ONE 32-byte record (the reference gathers id -> xy -> conic per batch
-// with dependent loads, forward.cu:318-326): written per Gaussian by the preprocess pass (index_rec, `pm` = radius), permuted into
-// depth-rank order for the binning passes (rank_rec), and what the blend kernels stage per list entry.
+// with dependent loads, forward.cu:318-326): written per VISIBLE Gaussian by the preprocess pass (index_rec, `pm` = radius; the
+// slots of culled Gaussians are not written -- depth_key says which), read in index order by the count / emit passes, and what the
+// blend kernels gather per list entry.
 struct __attribute__((aligned(16))) BlendRec {
     float2 xy;       // pixel-space mean
     uint32_t id;     // Gaussian index (feature row)
@@ -321,26 +334,21 @@ static_assert(sizeof(BlendRec) == 32, "BlendRec must be 32 bytes");
 __device__ __forceinline__ BlendRec list_record(const uint32_t* __restrict__ lst, const BlendRec* __restrict__ index_rec, int i)
 {
     const uint32_t e = lst[i];
-    BlendRec r = index_rec[e & RANK_MASK];
-    r.pm = ((uint32_t)i << 4) | (e >> RANK_BITS);
+    BlendRec r = index_rec[e & ID_MASK];
+    r.pm = ((uint32_t)i << 4) | (e >> ID_BITS);
     return r;
 }
 
-// ---- per-rank geometry records ------------------------------------------------------------------------
-// The per-Gaussian data the binning stages need (pixel mean, conic, opacity, radius, id) is written by the preprocess pass as ONE
-// 32-byte record per Gaussian (index_rec) and permuted once into depth-rank order by the depth sort (rank_rec, depth_sort.h): the count
-// and emit passes read the ranks coalesced; the blend kernels gather index_rec[id] per list entry they reach.
-
-// ---- 4. counting and rank emission -------------------------------------------------------------------
+// ---- counting and emission ------------------------------------------------------------------------------
 // Global atomics are the scarce resource of the binning stages (about 25 G scattered dword atomics/s on this part:
 // one corner atomic per Gaussian and one cursor atomic per overlap were 0.11 + 0.27 ms per view).  So the bucketing
-// is done the way a radix-sort pass does it.  The depth ranks are dealt to <= 512 workgroups of 1024 threads in
-// chunks of 64 ranks, round robin; the set of ranks a workgroup owns is its "slice":
+// is done the way a radix-sort pass does it.  The Gaussians are dealt to <= 256 workgroups of 1024 threads in
+// chunks of 64 consecutive indices, round robin; the set of chunks a workgroup owns is its "slice":
 //   count pass  (EMIT = false): per-tile counters in LDS, one LDS atomic per overlap; the counters go to
 //                partial[slice][tile] with plain stores;
 //   scan        (scan_partials_kernel): per tile, the exclusive prefix over slices (in place) and the tile total;
 //   emit pass   (EMIT = true): LDS cursors start at ranges[tile].x + partial[slice][tile]; every overlap takes
-//                its slot with a returning LDS atomic and stores its 4-byte depth rank.
+//                its slot with a returning LDS atomic and stores its 8-byte entry {depth bits, id | mask << 28}.
 // Both passes enumerate the overlaps with the same code, so the counts cannot disagree with the emission.  Inside a
 // tile the entries of one slice arrive in arbitrary order; the per-tile sort below does not care.
 inline int bin_workgroups(int P)
@@ -355,10 +363,11 @@ inline int bin_workgroups(int P)
 // kernels skip the entries without a mask bit.  NOCULL (testing aid, MI_RAST_NO_CULL): every overlap is kept with all four quadrant bits.
 // The product default does not come here: bin_spans_kernel below.
 template <bool NOCULL = false>
-__global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ rank_rec,
+__global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const BlendRec* __restrict__ index_rec,
+                                                                const uint32_t* __restrict__ depth_key,
                                                                 const uint32_t* __restrict__ partial,
                                                                 const uint2* __restrict__ ranges,
-                                                                uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy,
+                                                                uint2* __restrict__ entries, uint32_t gx, uint32_t gy,
                                                                 uint32_t by0, uint32_t by1)
 {
     // One launch covers the tile rows [by0, by1) (the whole image unless it has more tiles than LDS counters: then the host
@@ -373,12 +382,13 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
     RectWork rw{s_rw, s_rw + 1024, s_rw + 2048, s_rw + 3072};
     float2* s_xy = reinterpret_cast<float2*>(s_rw + 3088);          // the owners' means ...
     float4* s_co = reinterpret_cast<float4*>(s_rw + 3088 + 2048);   // ... conics + opacities ...
-    uint32_t* s_rad = s_rw + 3088 + 6144;                           // ... and radii
+    uint32_t* s_rad = s_rw + 3088 + 6144;                           // ... radii ...
+    uint32_t* s_key = s_rw + 3088 + 7168;                           // ... and depth bits
     const uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * ntiles_all + tile0;
     for (int t = tid; t < ntiles; t += BIN_THREADS) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
     __syncthreads();
-    // 64-rank chunks are dealt round robin over all the waves of all the workgroups: chunk c belongs to workgroup
-    // c % nwg, wave slot (c / nwg) % 16, round (c / nwg) / 16 -- the heavy (near) chunks end up in different workgroups
+    // 64-index chunks are dealt round robin over all the waves of all the workgroups: chunk c belongs to workgroup
+    // c % nwg, wave slot (c / nwg) % 16, round (c / nwg) / 16
     const int nwg = (int)gridDim.x;
     const int rounds = ((P + 63) / 64 + 16 * nwg - 1) / (16 * nwg);
     for (int it = 0; it < rounds; it++) {
@@ -386,23 +396,24 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
         uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
         uint32_t count = 0;
         if (r < P) {
-            const BlendRec rec = rank_rec[r];
-            const int rad = (int)rec.pm;
-            if (rad > 0) {
-                getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy);
+            const uint32_t key = depth_key[r];
+            if (key != 0xFFFFFFFFu) {   // visible (geometry.h: radius > 0), so its record was written
+                const BlendRec rec = index_rec[r];
+                getRect(rec.xy.x, rec.xy.y, (int)rec.pm, rmin, rmax, gx, gy);
                 rmin.y = max(rmin.y, by0);  // this band's rows only
                 rmax.y = min(rmax.y, by1);
                 count = rmax.y > rmin.y ? (rmax.x - rmin.x) * (rmax.y - rmin.y) : 0u;
+                s_xy[tid] = rec.xy;
+                s_co[tid] = rec.co;
+                s_rad[tid] = rec.pm;
+                s_key[tid] = key;
             }
-            s_xy[tid] = rec.xy;
-            s_co[tid] = rec.co;
-            s_rad[tid] = rec.pm;
         }
         for_each_tile_balanced(rw, tid, rmin, rmax, count, [&](uint32_t owner, uint32_t tx, uint32_t ty) {
             const uint32_t qmask = NOCULL ? 15u : span_tile_mask(s_xy[owner], s_co[owner], (int)s_rad[owner], tx, ty, gx, gy);
-            const uint32_t rank = (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
+            const uint32_t id = (uint32_t)(((it * 16 + (int)(owner >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(owner & 63u));
             const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
-            entries[slot] = rank | (qmask << RANK_BITS);
+            entries[slot] = make_uint2(s_key[owner], id | (qmask << ID_BITS));
         });
     }
 }
@@ -410,17 +421,21 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_ranks_kernel(int P, const Ble
 // Count pass without enumerating the overlaps: every rect adds +1 / -1 / -1 / +1 at its four corners of a
 // (gy + 1) x (gx + 1) difference grid in LDS (four LDS atomics per Gaussian instead of one per covered tile plus a
 // ten-step owner search), and a 2-D prefix sum of the grid is the number of rects covering each tile -- exactly what
-// an enumeration would count.  Same slices (rank chunks dealt round robin) and the same rects as bin_ranks_kernel: the count
+// an enumeration would count.  Same slices (index chunks dealt round robin) and the same rects as bin_ranks_kernel: the count
 // pass of the FULL lists.
 __host__ __device__ inline int count_grid_stride(uint32_t gx) { return (int)((gx + 1) | 1u); }  // odd row stride: column walks spread over the banks
 
-__global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const BlendRec* __restrict__ rank_rec,
+__global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const BlendRec* __restrict__ index_rec,
+                                                                const uint32_t* __restrict__ depth_key,
                                                                 uint32_t* __restrict__ partial, uint32_t gx, uint32_t gy_all,
-                                                                uint32_t by0, uint32_t by1)
+                                                                uint32_t by0, uint32_t by1, const int* __restrict__ r_slots,
+                                                                int* __restrict__ host_r)
 {
     // tile rows [by0, by1) of the image (see bin_ranks_kernel); the difference grid covers the band only
     extern __shared__ int s_grid[];  // [(band rows + 1) * stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the partial sums of R for the host (see bin_spans_kernel)
+    if (host_r != nullptr && blockIdx.x == 0 && tid < R_SLOTS) host_r[tid * R_SLOT_STRIDE] = r_slots[tid * R_SLOT_STRIDE];
     const int stride = count_grid_stride(gx);
     const uint32_t gy = by1 - by0;
     const int cells = (int)(gy + 1) * stride;
@@ -431,11 +446,10 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
     for (int it = 0; it < rounds; it++) {
         const int r = ((it * 16 + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
         if (r >= P) continue;
-        const BlendRec rec = rank_rec[r];
-        const int rad = (int)rec.pm;
-        if (rad <= 0) continue;
+        if (depth_key[r] == 0xFFFFFFFFu) continue;
+        const BlendRec rec = index_rec[r];
         uint2 rmin, rmax;
-        getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy_all);
+        getRect(rec.xy.x, rec.xy.y, (int)rec.pm, rmin, rmax, gx, gy_all);
         rmin.y = max(rmin.y, by0);
         rmax.y = min(rmax.y, by1);
         if (rmax.x <= rmin.x || rmax.y <= rmin.y) continue;
@@ -478,62 +492,47 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
 }
 
 // ---- lean lists from row spans (the product default) ------------------------------------------------------------
-// The count and emit passes of the lean lists without a single per-tile test.  Items of the first level are (Gaussian,
-// tile row) pairs, balanced over the workgroup like the tiles of bin_ranks_kernel (a Gaussian covers 1 .. 68 rows); each
-// evaluates the two closed-form column intervals of its row's upper and lower 8-pixel band (cull.h: band_columns) and
-// gets the tile span [x0, x1) that holds them.
-//   COUNT (EMIT = false): +1 / -1 at the two ends of the span in a per-row difference grid in LDS; the prefix along x is
-//                the number of spans covering each tile -- this slice's share of the tile's segment, EXACTLY: a tile is
-//                counted iff the emit pass stores an entry for it, so the segments have no unused slots;
-//   EMIT:        second level, the tiles of the 1024 spans of a window, balanced again: the quadrant mask of a tile is read
-//                off the two column intervals (four range tests on integers), the slot comes from the LDS cursor.
-// Measured on cfg3: 8.68 M tiles in the shrunk rects, 5.2 M in the spans; the enumerating emit pass spent 182 VALU
-// instructions per 64 rect tiles on the whole-tile test and 386 per 64 survivors on the four quadrant tests.
-// Slices (rank chunks dealt round robin), partial[][] and the cursors are those of bin_count_kernel / bin_ranks_kernel.
-// LDS words of the hand-off arrays of a workgroup of nt threads: RectWork + means + conics + prefix / rect / radius / two bands' columns
-__host__ __device__ constexpr int span_lds_words(int nt) { return (3 * nt + 16) + 2 * nt + 4 * nt + 5 * nt; }
-constexpr int SPAN_LDS_WORDS = span_lds_words(1024);
-// Threads per workgroup of the LEAN count / emit passes.  512 (profiling build, MI_RAST_BIN_NT): two workgroups share a CU (2 x 61 KB of
-// LDS at 1080p) and overlap each other's workgroup-barrier phases, at the price of twice as many rank slices.  Measured in round 5
-// (profiles/r05_front_half.md): emit 0.071 -> 0.065 ms, but count + scans 0.057 -> 0.068 (the partial[][] table and its scan double):
-// 1024 stays.
-constexpr int BIN_LEAN_THREADS = 1024;
-constexpr int BIN_LEAN_MAX_WG = 512;
-inline int bin_lean_workgroups(int P, int nt)
-{
-    const int blocks = (P + nt - 1) / nt;
-    const int cap = nt == 1024 ? BIN_MAX_WG : BIN_LEAN_MAX_WG;
-    return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
-}
+// The count and emit passes of the lean lists without a single per-tile test, WAVE-GRANULAR (round 6).  A wave takes a chunk of
+// 64 consecutive Gaussians (the next chunk of its workgroup's slice from an LDS counter; its records are requested one chunk
+// ahead), and walks
+//   level 1: the (Gaussian, tile row) items of the chunk, 64 at a time, balanced over the lanes (a Gaussian covers 1 .. 68
+//            rows): item k belongs to the lane whose inclusive prefix of row counts first exceeds k -- a six-step search in a
+//            wave-private LDS copy of the prefix.  Each item evaluates the two closed-form column intervals of its row's upper
+//            and lower 8-pixel band (cull.h: band_columns) and gets the tile span [x0, x1) that holds them;
+//   COUNT (EMIT = false): +1 / -1 at the two ends of the span in a per-row difference grid in LDS (shared by the workgroup's
+//            16 waves: LDS atomics); the prefix along x is the number of spans covering each tile -- this slice's share of the
+//            tile's segment, EXACTLY: a tile is counted iff the emit pass stores an entry for it;
+//   EMIT:    level 2, the tiles of the 64 spans of a window, balanced again: the quadrant mask of a tile is read off the two
+//            column intervals (four range tests on integers), the slot comes from the LDS cursor of the tile.
+// The waves of a workgroup share nothing but the counters / cursors: no workgroup barrier between the first store of a
+// counter and the last (rounds 2-5 ran this as 1024-thread phases between workgroup barriers: count 0.036 ms, emit 0.071 ms
+// on cfg3, ~1 us per phase whatever it computed).  Hand-offs between the lanes of a wave go through wave-private LDS words;
+// LDS operations of one wave execute in program order, the wavefront fences keep the compiler from reordering them.
+// Measured on cfg3: 2.27 M (Gaussian, row) items, 2.93 M entries.
+constexpr int BW_WORDS = 64 * 14;  // LDS words per wave: prefix, rect, radius, depth bits, mean (2), conic + opacity (4); emit: span prefix, two bands' columns, span origin
+__host__ __device__ constexpr size_t span_lds_bytes(size_t head_words) { return (((head_words + 3) & ~(size_t)3) + 4 + 16 * BW_WORDS) * sizeof(uint32_t); }
 
-template <int NT = 1024>
-__device__ __forceinline__ uint32_t workgroup_inclusive_scan(uint32_t v, int tid, uint32_t* s_wsum, uint32_t& total)
+// first slot g of a wave-private inclusive prefix (64 words) with pre[g] > k; k < pre[63]
+__device__ __forceinline__ int wave_owner(const uint32_t* pre, uint32_t k)
 {
-    const int lane = tid & 63, wave = tid >> 6;
-    uint32_t incl = wave_inclusive_scan(v, lane);
-    __syncthreads();  // s_wsum may still be read by the previous caller
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
+    int g = 0;
 #pragma unroll
-    for (int w = 0; w < NT / 64; w++) {
-        const uint32_t c = s_wsum[w];
-        woff += w < wave ? c : 0u;
-        tot += c;
-    }
-    total = tot;
-    return incl + woff;
+    for (int step = 32; step >= 1; step >>= 1)
+        if (pre[g + step - 1] <= k) g += step;
+    return g;
 }
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-template <bool EMIT, int NT = 1024>
-__global__ void __launch_bounds__(NT) bin_spans_kernel(int P, const BlendRec* __restrict__ rank_rec,
-                                                                uint32_t* __restrict__ partial,
-                                                                const uint2* __restrict__ ranges,
-                                                                uint32_t* __restrict__ entries, uint32_t gx, uint32_t gy_all,
-                                                                uint32_t by0, uint32_t by1, int ablate)
+template <bool EMIT>
+__global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* __restrict__ index_rec,
+                                                         const uint32_t* __restrict__ depth_key,
+                                                         uint32_t* __restrict__ partial, const uint2* __restrict__ ranges,
+                                                         uint2* __restrict__ entries, uint32_t gx, uint32_t gy_all,
+                                                         uint32_t by0, uint32_t by1, const int* __restrict__ r_slots,
+                                                         int* __restrict__ host_r, int ablate)
 {
-    // COUNT: s_dyn = difference grid [band rows][stride] (ints), then the hand-off arrays
-    // EMIT : s_dyn = cursors [band tiles], then the hand-off arrays
+    // COUNT: s_dyn = difference grid [band rows][stride] (ints), then the chunk counter and the waves' hand-off words
+    // EMIT : s_dyn = cursors [band tiles], then the same
     extern __shared__ uint32_t s_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t gy = by1 - by0;
@@ -544,82 +543,100 @@ __global__ void __launch_bounds__(NT) bin_spans_kernel(int P, const BlendRec* __
     const int head = EMIT ? ((ntiles + 3) & ~3) : (((int)gy * stride + 3) & ~3);
     uint32_t* s_cnt = s_dyn;
     int* s_grid = reinterpret_cast<int*>(s_dyn);
-    uint32_t* s_rw = s_dyn + head;
-    constexpr int NW = NT / 64;              // waves per workgroup
-    static_assert(NT == 1024 || NT == 512, "rank slices are dealt in 64-rank chunks to 16 or 8 waves");
-    RectWork rw{s_rw, s_rw + NT, s_rw + 2 * NT, s_rw + 3 * NT};
-    float2* s_xy = reinterpret_cast<float2*>(s_rw + 3 * NT + 16);
-    float4* s_co = reinterpret_cast<float4*>(s_rw + 3 * NT + 16 + 2 * NT);
-    uint32_t* s_gpre = s_rw + 3 * NT + 16 + 6 * NT;   // inclusive prefix of the Gaussians' row counts
-    uint32_t* s_grect = s_gpre + NT;         // clip columns x0 | x1 << 10, first row << 21
-    uint32_t* s_grad = s_grect + NT;         // radius (the margin of tau needs it)
-    uint32_t* s_q0 = s_grad + NT;            // EMIT, per span: upper band's columns lo | hi << 11, Gaussian slot << 22
-    uint32_t* s_q1 = s_q0 + NT;              //                 lower band's columns lo | hi << 11
+    uint32_t* s_next = s_dyn + head;   // [4]: next chunk of the slice
+    uint32_t* wb = s_dyn + head + 4 + wave * BW_WORDS;
+    uint32_t* w_pre = wb;              // inclusive prefix of the lanes' row counts
+    uint32_t* w_rect = wb + 64;        // clip columns x0 | x1 << 10, first row << 21
+    uint32_t* w_rad = wb + 128;        // radius (the margin of tau needs it)
+    uint32_t* w_key = wb + 192;        // depth bits
+    float2* w_xy = reinterpret_cast<float2*>(wb + 256);
+    float4* w_co = reinterpret_cast<float4*>(wb + 384);
+    uint32_t* w_tpre = wb + 640;       // EMIT, per span of the window: inclusive prefix of the spans' widths
+    uint32_t* w_q0 = wb + 704;         //   upper band's columns lo | hi << 11, owner lane << 22
+    uint32_t* w_q1 = wb + 768;         //   lower band's columns lo | hi << 11
+    uint32_t* w_sx = wb + 832;         //   first tile column | tile row << 10
+    // The first kernel behind the preprocess pass hands the partial sums of R to the host: plain stores into its pinned buffer
+    // (a copy command of 8 KB costs a 5-us blit kernel on the stream); the event behind this kernel tells the host they are there.
+    if (!EMIT && host_r != nullptr && blockIdx.x == 0 && tid < R_SLOTS) host_r[tid * R_SLOT_STRIDE] = r_slots[tid * R_SLOT_STRIDE];
     uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * ntiles_all + tile0;
     if (EMIT) {
-        for (int t = tid; t < ntiles; t += NT) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
+        for (int t = tid; t < ntiles; t += 1024) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
     } else {
-        for (int c = tid; c < (int)gy * stride; c += NT) s_grid[c] = 0;
+        for (int c = tid; c < (int)gy * stride; c += 1024) s_grid[c] = 0;
     }
+    if (tid == 0) s_next[0] = 16u;   // (the first 16 chunks of the slice go to the waves by their number)
     __syncthreads();
     const int nwg = (int)gridDim.x;
-    const int rounds = ((P + 63) / 64 + NW * nwg - 1) / (NW * nwg);   // 64-rank chunks dealt round robin over all waves of all workgroups
-    // The record of the NEXT round is requested before this round's items are walked (a round is a chain of workgroup barriers
-    // and LDS searches with one workgroup per CU: nothing else would hide the load).  Unconditional, index clamped: a
-    // conditionally assigned load result is waited for on the spot.
-    BlendRec nxt = rank_rec[min((wave * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
-    for (int it = 0; it < rounds; it++) {
-        const int r = ((it * NW + wave) * nwg + (int)blockIdx.x) * 64 + lane;  // same dealing as bin_ranks_kernel
-        const BlendRec rec = nxt;
-        nxt = rank_rec[min((((it + 1) * NW + wave) * nwg + (int)blockIdx.x) * 64 + lane, P - 1)];
+    const int nchunks = (P + 63) / 64;
+    // chunk j of this slice is chunk j * nwg + blockIdx.x of the view
+    const int nloc = (int)blockIdx.x < nchunks ? (nchunks - (int)blockIdx.x + nwg - 1) / nwg : 0;
+    int j = wave;
+    uint32_t nkey = 0xFFFFFFFFu;
+    BlendRec nrec;
+    {
+        const int i = min((j * nwg + (int)blockIdx.x) * 64 + lane, P - 1);
+        nrec = index_rec[i];
+        nkey = depth_key[i];
+    }
+    while (j < nloc) {
+        const int chunk = j * nwg + (int)blockIdx.x;
+        const int i = chunk * 64 + lane;
+        const BlendRec rec = nrec;
+        const uint32_t key = nkey;
+        // next chunk of the slice: taken now, its records requested before this chunk's items are walked (unconditional loads,
+        // index clamped: a conditionally assigned load result is waited for on the spot)
+        uint32_t jn = 0;
+        if (lane == 0) jn = atomicAdd(s_next, 1u);
+        j = (int)__builtin_amdgcn_readfirstlane(jn);
+        {
+            const int in = min((min(j, nloc > 0 ? nloc - 1 : 0) * nwg + (int)blockIdx.x) * 64 + lane, P - 1);
+            nrec = index_rec[in];
+            nkey = depth_key[in];
+        }
         uint32_t h = 0;
-        if (r < P) {
+        if (i < P && key != 0xFFFFFFFFu) {   // visible: radius > 0, record written (geometry.h)
             const int rad = (int)rec.pm;
-            if (rad > 0) {
-                uint2 rmin, rmax;
-                getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy_all);
-                shrink_rect(rec.xy, rec.co, rad, rmin, rmax);
-                rmin.y = max(rmin.y, by0);
-                rmax.y = min(rmax.y, by1);
-                if (rmax.x > rmin.x && rmax.y > rmin.y) {
-                    h = rmax.y - rmin.y;
-                    s_xy[tid] = rec.xy;
-                    s_co[tid] = rec.co;
-                    s_grect[tid] = rmin.x | (rmax.x << 10) | (rmin.y << 21);
-                    s_grad[tid] = (uint32_t)rad;
-                }
+            uint2 rmin, rmax;
+            getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy_all);
+            shrink_rect(rec.xy, rec.co, rad, rmin, rmax);
+            rmin.y = max(rmin.y, by0);
+            rmax.y = min(rmax.y, by1);
+            if (rmax.x > rmin.x && rmax.y > rmin.y) {
+                h = rmax.y - rmin.y;
+                w_xy[lane] = rec.xy;
+                w_co[lane] = rec.co;
+                w_rect[lane] = rmin.x | (rmax.x << 10) | (rmin.y << 21);
+                w_rad[lane] = (uint32_t)rad;
+                if (EMIT) w_key[lane] = key;
             }
         }
-        uint32_t rows_total;
-        s_gpre[tid] = workgroup_inclusive_scan<NT>(h, tid, rw.wsum, rows_total);
-        __syncthreads();
+        const uint32_t hincl = wave_inclusive_scan(h, lane);
+        uint32_t rows_total = (uint32_t)__shfl((int)hincl, 63, 64);
+        w_pre[lane] = hincl;
+        wave_lds_fence();
         if MI_ABLATE(1 << 20) rows_total = 0;
-        for (uint32_t w0 = 0; w0 < rows_total; w0 += NT) {  // windows of NT (Gaussian, tile row) items
-            const uint32_t k = w0 + (uint32_t)tid;
-            uint2 smin = make_uint2(0, 0), smax = make_uint2(0, 0);
+        for (uint32_t w0 = 0; w0 < rows_total; w0 += 64) {  // windows of 64 (Gaussian, tile row) items
+            const uint32_t k = w0 + (uint32_t)lane;
             uint32_t width = 0;
             if (k < rows_total) {
-                int g = 0;  // first Gaussian slot with prefix > k
-#pragma unroll
-                for (int step = NT / 2; step >= 1; step >>= 1)
-                    if (s_gpre[g + step - 1] <= k) g += step;
-                const uint32_t prev = g == 0 ? 0u : s_gpre[g - 1];
-                const uint32_t packed = s_grect[g];
+                const int g = wave_owner(w_pre, k);
+                const uint32_t prev = g == 0 ? 0u : w_pre[g - 1];
+                const uint32_t packed = w_rect[g];
                 const uint32_t cx0 = packed & 1023u, cx1 = (packed >> 10) & 2047u, ty = (packed >> 21) + (k - prev);
-                const float2 xy = s_xy[g];
-                const SpanPre pre = span_prepare(s_co[g], (int)s_grad[g]);
+                const float2 xy = w_xy[g];
+                const SpanPre pre = span_prepare(w_co[g], (int)w_rad[g]);
                 int lo0, hi0, lo1, hi1;
                 band_columns(pre, xy, (float)(ty * TILE_Y), (int)(2u * cx0), (int)(2u * cx1), lo0, hi0);
                 band_columns(pre, xy, (float)(ty * TILE_Y + 8u), (int)(2u * cx0), (int)(2u * cx1), lo1, hi1);
                 if (hi0 > lo0 || hi1 > lo1) {
                     const int lo = hi0 > lo0 ? (hi1 > lo1 ? min(lo0, lo1) : lo0) : lo1;
                     const int hi = hi0 > lo0 ? (hi1 > lo1 ? max(hi0, hi1) : hi0) : hi1;
-                    smin = make_uint2((uint32_t)lo >> 1, ty);
-                    smax = make_uint2(((uint32_t)hi + 1u) >> 1, ty + 1u);
-                    width = smax.x - smin.x;
+                    const uint32_t sx0 = (uint32_t)lo >> 1, sx1 = ((uint32_t)hi + 1u) >> 1;
                     if (EMIT) {
-                        s_q0[tid] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | ((uint32_t)g << 22);
-                        s_q1[tid] = (uint32_t)lo1 | ((uint32_t)hi1 << 11);
+                        width = sx1 - sx0;
+                        w_q0[lane] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | ((uint32_t)g << 22);
+                        w_q1[lane] = (uint32_t)lo1 | ((uint32_t)hi1 << 11);
+                        w_sx[lane] = sx0 | (ty << 10);
                     } else {
                         // EXACT counts: a tile is counted iff one of the two intervals has a column in it, i.e. iff the emit
                         // pass finds a non-zero mask there -- the two bands' tile ranges separately when a gap lies between them
@@ -631,39 +648,44 @@ __global__ void __launch_bounds__(NT) bin_spans_kernel(int P, const BlendRec* __
                             atomicAdd(&row[a1], 1);
                             atomicAdd(&row[b1], -1);
                         } else {
-                            atomicAdd(&row[smin.x], 1);
-                            atomicAdd(&row[smax.x], -1);
+                            atomicAdd(&row[sx0], 1);
+                            atomicAdd(&row[sx1], -1);
                         }
                     }
                 }
             }
             if (EMIT && !MI_ABLATE(1 << 16)) {
-                for_each_tile_balanced<NT>(
-                    rw, tid, smin, smax, width,
-                    [&](uint32_t owner, uint32_t tx, uint32_t ty) {
-                        if MI_ABLATE(1 << 17) return;
-                        const uint32_t q0 = s_q0[owner], q1 = s_q1[owner];
+                const uint32_t tincl = wave_inclusive_scan(width, lane);
+                const uint32_t tiles_total = (uint32_t)__shfl((int)tincl, 63, 64);
+                w_tpre[lane] = tincl;
+                wave_lds_fence();
+                for (uint32_t t0 = 0; t0 < tiles_total; t0 += 64) {   // windows of 64 tiles of the spans
+                    const uint32_t kk = t0 + (uint32_t)lane;
+                    if (kk < tiles_total) {
+                        const int o = wave_owner(w_tpre, kk);
+                        const uint32_t prevt = o == 0 ? 0u : w_tpre[o - 1];
+                        const uint32_t q0 = w_q0[o], q1 = w_q1[o], sx = w_sx[o];
+                        const uint32_t tx = (sx & 1023u) + (kk - prevt), ty = sx >> 10;
                         const uint32_t lo0 = q0 & 2047u, n0 = ((q0 >> 11) & 2047u) - lo0, lo1 = q1 & 2047u, n1 = ((q1 >> 11) & 2047u) - lo1;
                         const uint32_t c = 2u * tx;
                         const uint32_t qmask = (uint32_t)(c - lo0 < n0) | ((uint32_t)(c + 1u - lo0 < n0) << 1) |
                                                ((uint32_t)(c - lo1 < n1) << 2) | ((uint32_t)(c + 1u - lo1 < n1) << 3);
                         if (qmask != 0u) {
-                            const uint32_t slot_g = q0 >> 22;
-                            const uint32_t rank = (uint32_t)(((it * NW + (int)(slot_g >> 6)) * nwg + (int)blockIdx.x) * 64 + (int)(slot_g & 63u));
-                            if MI_ABLATE(1 << 18) return;
+                            const uint32_t g = q0 >> 22;
                             const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
-                            if MI_ABLATE(1 << 19) return;
-                            entries[slot] = rank | (qmask << RANK_BITS);
+                            entries[slot] = make_uint2(w_key[g], (uint32_t)(chunk * 64 + (int)g) | (qmask << ID_BITS));
                         }
-                    });
+                    }
+                }
+                wave_lds_fence();   // the spans' words are rewritten by the next window
             }
         }
-        __syncthreads();  // the Gaussian arrays are rewritten by the next round
+        wave_lds_fence();   // the Gaussians' words are rewritten by the next chunk
     }
     if (!EMIT) {
         __syncthreads();
         // prefix along x: one wave per row, 64 cells at a time with a carry -> the per-tile counts of this slice
-        for (int y = wave; y < (int)gy; y += NW) {
+        for (int y = wave; y < (int)gy; y += 16) {
             int carry = 0;
             for (int x0 = 0; x0 < (int)gx; x0 += 64) {
                 const int x = x0 + lane;
@@ -708,18 +730,37 @@ __global__ void __launch_bounds__(1024) scan_partials_kernel(int ntiles, int nwg
     }
 }
 
-// ---- 5. per-tile LDS radix sort of the ranks --------------------------------------------------------
+// ---- per-tile LDS radix sort of the entries by depth bits ------------------------------------------------
+// (key, value) pair storage: two LDS arrays, or one uint2 array in HBM
+struct LdsPairs {
+    uint32_t* k;
+    uint32_t* v;
+    __device__ __forceinline__ uint32_t key(int i) const { return k[i]; }
+    __device__ __forceinline__ uint32_t val(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, uint32_t kk, uint32_t vv) const
+    {
+        k[i] = kk;
+        v[i] = vv;
+    }
+};
+struct GlobalPairs {
+    uint2* p;
+    __device__ __forceinline__ uint32_t key(int i) const { return p[i].x; }
+    __device__ __forceinline__ uint32_t val(int i) const { return p[i].y; }
+    __device__ __forceinline__ void set(int i, uint32_t kk, uint32_t vv) const { p[i] = make_uint2(kk, vv); }
+};
+
 // One workgroup (256 threads for short lists, 1024 for long ones) per tile; handles tiles with LO < n <= CAP in LDS; when GLOBAL_FALLBACK is set it
 // also handles n > CAP by ping-ponging between `entries` and `scratch` in HBM with the same code.
-// LSD radix, 8-bit digits, `passes` = ceil(rank_bits / 8).  Each wave owns a contiguous quarter of the tile's
-// list; per pass: per-wave digit histograms -> workgroup scan over (digit, wave) -> each wave scatters its quarter
-// 64 keys at a time with a stable ballot-match rank.  Three workgroup barriers per pass.
-// MAXB > 0 (lists held in LDS: a wave's share is at most MAXB batches of 64 keys): the keys and their match results
+// LSD radix over the depth bits, 8-bit digits, ceil(key_bits / 8) passes (key_bits: the low bits in which the view's keys differ,
+// from the range scan).  Each wave owns a contiguous share of the tile's list; per pass: per-wave digit histograms -> workgroup scan
+// over (digit, wave) -> each wave scatters its share 64 pairs at a time with a stable ballot-match rank.  Three workgroup barriers per pass.
+// MAXB > 0 (lists held in LDS: a wave's share is at most MAXB batches of 64 pairs): the pairs and their match results
 // (rank among the wave's equal digits, size of that group) stay in registers between the histogram and the scatter
-// phase -- the eight-ballot match is evaluated once per key and pass instead of twice.  MAXB = 0: any length (the
+// phase -- the eight-ballot match is evaluated once per pair and pass instead of twice.  MAXB = 0: any length (the
 // HBM fallback), everything re-read and re-matched in the scatter phase.
-template <int NW, int MAXB, typename SrcPtr, typename DstPtr>
-__device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int shift, uint32_t (*s_hist)[256], int tid)
+template <int NW, int MAXB, typename Src, typename Dst>
+__device__ __forceinline__ void radix_pass(Src src, Dst dst, int n, int shift, uint32_t (*s_hist)[256], int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
     // contiguous share per wave (NW waves), in multiples of 64 keys
@@ -741,7 +782,7 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
     };
 
     constexpr int NB = MAXB > 0 ? MAXB : 1;
-    uint32_t c_key[NB], c_rk[NB], c_cnt[NB];
+    uint32_t c_key[NB], c_val[NB], c_rk[NB], c_cnt[NB];
     // (a) per-wave histogram of this digit
     if (MAXB > 0) {
 #pragma unroll
@@ -750,8 +791,9 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
             if (i0 >= end) break;  // wave-uniform
             const int i = i0 + lane;
             const bool active = i < end;
-            c_key[j] = active ? (uint32_t)src[i] : 0u;
-            const uint32_t digit = ((c_key[j] & RANK_MASK) >> shift) & 0xFFu;
+            c_key[j] = active ? src.key(i) : 0u;
+            c_val[j] = active ? src.val(i) : 0u;
+            const uint32_t digit = (c_key[j] >> shift) & 0xFFu;
             match(digit, active, c_rk[j], c_cnt[j]);
             if (active && c_rk[j] == 0) s_hist[wave][digit] += c_cnt[j];  // one lane per distinct digit, wave-private row
         }
@@ -759,8 +801,8 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
         for (int i0 = begin; i0 < end; i0 += 64) {
             const int i = i0 + lane;
             const bool active = i < end;
-            const uint32_t key = active ? (uint32_t)src[i] : 0u;
-            const uint32_t digit = ((key & RANK_MASK) >> shift) & 0xFFu;
+            const uint32_t key = active ? src.key(i) : 0u;
+            const uint32_t digit = (key >> shift) & 0xFFu;
             uint32_t rk, cnt;
             match(digit, active, rk, cnt);
             if (active && rk == 0) s_hist[wave][digit] += cnt;
@@ -793,13 +835,13 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
     }
     __syncthreads();
     // (c) stable scatter of this wave's share; s_hist[wave][digit] is now this wave's running cursor
-    auto scatter = [&](uint32_t key, bool active, uint32_t rk, uint32_t cnt) {
-        const uint32_t digit = ((key & RANK_MASK) >> shift) & 0xFFu;
+    auto scatter = [&](uint32_t key, uint32_t val, bool active, uint32_t rk, uint32_t cnt) {
+        const uint32_t digit = (key >> shift) & 0xFFu;
         uint32_t off = 0;
         if (active) off = s_hist[wave][digit] + rk;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (active && rk == cnt - 1) s_hist[wave][digit] = off + 1;  // last lane of the group advances the cursor
-        if (active) dst[off] = key;
+        if (active) dst.set((int)off, key, val);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
     if (MAXB > 0) {
@@ -807,37 +849,48 @@ __device__ __forceinline__ void radix_pass(SrcPtr src, DstPtr dst, int n, int sh
         for (int j = 0; j < NB; j++) {
             const int i0 = begin + 64 * j;
             if (i0 >= end) break;
-            scatter(c_key[j], i0 + lane < end, c_rk[j], c_cnt[j]);
+            scatter(c_key[j], c_val[j], i0 + lane < end, c_rk[j], c_cnt[j]);
         }
     } else {
         for (int i0 = begin; i0 < end; i0 += 64) {
             const int i = i0 + lane;
             const bool active = i < end;
-            const uint32_t key = active ? (uint32_t)src[i] : 0u;
+            const uint32_t key = active ? src.key(i) : 0u, val = active ? src.val(i) : 0u;
             uint32_t rk, cnt;
-            match(((key & RANK_MASK) >> shift) & 0xFFu, active, rk, cnt);
-            scatter(key, active, rk, cnt);
+            match((key >> shift) & 0xFFu, active, rk, cnt);
+            scatter(key, val, active, rk, cnt);
         }
     }
     __syncthreads();
 }
 
-// The tile's BLEND LIST: the sorted entries with the depth rank replaced by the Gaussian id, id | quadrant mask << 28, four bytes
-// per overlap at blend_list[range.x ...].  This is all the blend kernels get of a tile: they scan the entries 64 at a time (256
+// The tile's BLEND LIST: the values of the sorted entries, Gaussian id | quadrant mask << 28, four bytes per overlap at
+// blend_list[range.x ...].  This is all the blend kernels get of a tile: they scan the entries 64 at a time (256
 // contiguous bytes), queue the ones whose bit for their quadrant is set and gather the 32-byte geometry record index_rec[id] next to
-// the feature row of the same id -- two independent gathers behind one scan.  (Rounds 1-4 materialised a 32-byte blend record per
-// entry here: a 94-MB gather and a 94-MB store per cfg3 view for lists of which the blends walk a third.)  The position of an entry
+// the feature row of the same id -- two independent gathers behind one scan.  The position of an entry
 // in its list is its index -- n_contrib's unit.  Full lists (bin_ranks_kernel): every overlap of the reference's rects is an entry,
-// culled ones with mask 0, so blend_list & RANK_MASK IS the reference's point_list and the index its position there; lean lists
+// culled ones with mask 0, so blend_list & ID_MASK IS the reference's point_list and the index its position there; lean lists
 // (bin_spans_kernel): the entries that can blend only.
-template <int NW, typename SrcPtr>
-__device__ __forceinline__ void emit_blend_list(SrcPtr sorted_entries, int n, uint2 range, int tid,
-                                                const uint32_t* __restrict__ sorted_idx, uint32_t* __restrict__ blend_list)
+// The radix passes order by depth bits and keep the ARRIVAL order of equal keys, which is arbitrary; the contract orders equal depths
+// by Gaussian index (the reference's stable sort of (tile | depth) keys emitted in index order, rasterizer_impl.cu:96-113, 300-308).
+// Entries whose neighbour in the sorted list has the same key -- two Gaussians of one tile at bit-identical depth: rare, but not
+// excluded -- find their run and take the position of their id inside it.
+template <int NW, typename Src>
+__device__ __forceinline__ void emit_blend_list(Src sorted, int n, uint2 range, int tid, uint32_t* __restrict__ blend_list)
 {
     uint32_t* out = blend_list + range.x;
     for (int i = tid; i < n; i += NW * 64) {
-        const uint32_t e = sorted_entries[i];
-        out[i] = sorted_idx[e & RANK_MASK] | (e & ~RANK_MASK);
+        const uint32_t k = sorted.key(i), v = sorted.val(i);
+        int pos = i;
+        if ((i > 0 && sorted.key(i - 1) == k) || (i + 1 < n && sorted.key(i + 1) == k)) {
+            int lo = i, hi = i + 1;
+            while (lo > 0 && sorted.key(lo - 1) == k) lo--;
+            while (hi < n && sorted.key(hi) == k) hi++;
+            int before = 0;
+            for (int q = lo; q < hi; q++) before += (sorted.val(q) & ID_MASK) < (v & ID_MASK) ? 1 : 0;
+            pos = lo + before;
+        }
+        out[pos] = v;
     }
 }
 
@@ -846,61 +899,58 @@ __device__ __forceinline__ void emit_blend_list(SrcPtr sorted_entries, int n, ui
 // the flag the entries are zero-filled before the emit pass and this kernel counts the slots of every tile's segment that
 // are still zero afterwards (a lean entry always carries a non-zero quadrant mask): any such slot is a decision that differed.
 __global__ void __launch_bounds__(256) verify_entries_kernel(uint32_t ntiles, const uint2* __restrict__ ranges,
-                                                              const uint32_t* __restrict__ entries, uint32_t* __restrict__ unwritten)
+                                                              const uint2* __restrict__ entries, uint32_t* __restrict__ unwritten)
 {
     const uint32_t tile = blockIdx.x;
     if (tile >= ntiles) return;
     const uint2 r = ranges[tile];
     uint32_t n = 0;
-    for (uint32_t i = r.x + threadIdx.x; i < r.y; i += 256) n += entries[i] == 0u;
+    for (uint32_t i = r.x + threadIdx.x; i < r.y; i += 256) n += entries[i].y == 0u;
     if (n) atomicAdd(unwritten, n);
 }
 
 template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT>
 __global__ void __launch_bounds__(NT) tile_sort_kernel(uint32_t ntiles, const uint2* __restrict__ ranges,
-                                                        uint32_t* __restrict__ entries,
-                                                        uint32_t* __restrict__ scratch,
-                                                        const uint32_t* __restrict__ sorted_idx, int passes,
-                                                        uint32_t* __restrict__ blend_list)
+                                                        uint2* __restrict__ entries, uint2* __restrict__ scratch,
+                                                        const int* __restrict__ key_bits, uint32_t* __restrict__ blend_list)
 {
-    __shared__ uint32_t s_a[CAP];
-    __shared__ uint32_t s_b[CAP];
+    __shared__ uint32_t s_k[2][CAP];
+    __shared__ uint32_t s_v[2][CAP];
     constexpr int NW = NT / 64;
     __shared__ uint32_t s_hist[NW][256];
     const int tid = threadIdx.x;
-    // (tile = workgroup id: neighbouring tiles on different XCDs.  Contiguous runs per XCD -- common.h -- save 3 % here through
-    // the rank records neighbouring tiles share, but the cost of a tile is its list length, and a static split would let a
-    // scene's dense half wait for two of the eight XCDs.)
+    // (tile = workgroup id: neighbouring tiles on different XCDs.  The cost of a tile is its list length, and a static split into
+    // contiguous runs per XCD -- common.h -- would let a scene's dense half wait for two of the eight XCDs.)
     const uint32_t tile = blockIdx.x;
     if (tile >= ntiles) return;
     const uint2 range = ranges[tile];
+    const int passes = (*key_bits + 7) >> 3;
     const int n = (int)(range.y - range.x);
     if (n <= LO) return;
     if (n > CAP && !GLOBAL_FALLBACK) return;
-    uint32_t* seg = entries + range.x;
+    uint2* seg = entries + range.x;
     if (n <= CAP) {
         // (lean lists too: their counts are exact -- bin_spans_kernel --, every slot of the segment holds an entry)
-        for (int i = tid; i < n; i += NT) s_a[i] = seg[i];
+        for (int i = tid; i < n; i += NT) {
+            const uint2 e = seg[i];
+            s_k[0][i] = e.x;
+            s_v[0][i] = e.y;
+        }
         __syncthreads();
-        uint32_t* a = s_a;
-        uint32_t* b = s_b;
-        for (int p = 0; p < passes; p++) {
-            radix_pass<NW, (CAP + NW * 64 - 1) / (NW * 64)>(a, b, n, 8 * p, s_hist, tid);
-            uint32_t* t = a;
-            a = b;
-            b = t;
-        }
-        emit_blend_list<NW>(a, n, range, tid, sorted_idx, blend_list);
+        int cur = 0;
+        for (int p = 0; p < passes; p++, cur ^= 1)
+            radix_pass<NW, (CAP + NW * 64 - 1) / (NW * 64)>(LdsPairs{s_k[cur], s_v[cur]}, LdsPairs{s_k[cur ^ 1], s_v[cur ^ 1]}, n, 8 * p, s_hist, tid);
+        emit_blend_list<NW>(LdsPairs{s_k[cur], s_v[cur]}, n, range, tid, blend_list);
     } else {
-        uint32_t* a = seg;
-        uint32_t* b = scratch + range.x;
+        uint2* a = seg;
+        uint2* b = scratch + range.x;
         for (int p = 0; p < passes; p++) {
-            radix_pass<NW, 0>(a, b, n, 8 * p, s_hist, tid);
-            uint32_t* t = a;
+            radix_pass<NW, 0>(GlobalPairs{a}, GlobalPairs{b}, n, 8 * p, s_hist, tid);
+            uint2* t = a;
             a = b;
             b = t;
         }
-        emit_blend_list<NW>(a, n, range, tid, sorted_idx, blend_list);
+        emit_blend_list<NW>(GlobalPairs{a}, n, range, tid, blend_list);
     }
 }
 

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                 const int q = tid + BATCH * k;
                 const int g = q / F4, part = q % F4;
                 if (g < nr)
-                    s_feat4[g * F4 + part] = reinterpret_cast<const float4*>(colors + (size_t)(lst[NS - 1 - (b0 + g)] & RANK_MASK) * C)[part];
+                    s_feat4[g * F4 + part] = reinterpret_cast<const float4*>(colors + (size_t)(lst[NS - 1 - (b0 + g)] & ID_MASK) * C)[part];
             }
         }
         if constexpr (C > 0 && !WIDE)

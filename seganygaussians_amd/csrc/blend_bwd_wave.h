@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     // walked is below the quadrant's largest n_contrib: NS <= wave_Lt); requests the next block.
     auto consume_scan = [&]() {
         const int j = scanned + lane;
-        const bool cand = j < NS && ((scan_reg >> (RANK_BITS + quad)) & 1u) != 0;
+        const bool cand = j < NS && ((scan_reg >> (ID_BITS + quad)) & 1u) != 0;
         const uint64_t bal = ballot64(cand);
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg);
@@ -229,14 +229,14 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         asm volatile("" : "+v"(l));
         {
             const int rq = min(l >> 2, n - 1), qq = l & 3;
-            const uint32_t gq = s_queue[(qh + rq) & (QCAP - 1)].y & RANK_MASK;
+            const uint32_t gq = s_queue[(qh + rq) & (QCAP - 1)].y & ID_MASK;
             curq = reinterpret_cast<const uint2*>(index_rec + gq)[qq];
         }
 #pragma unroll
         for (int k = 0; k < NK; k++) {
             const int e = l + 64 * k;
             const int g = min(e / F4, n - 1), part = e % F4;
-            const size_t gid = (size_t)(s_queue[(qh + g) & (QCAP - 1)].y & RANK_MASK);
+            const size_t gid = (size_t)(s_queue[(qh + g) & (QCAP - 1)].y & ID_MASK);
             if constexpr (CR == C) {
                 featpf[k] = reinterpret_cast<const float4*>(colors + gid * (size_t)cstride)[part];
             } else if constexpr (CR == 0) {  // partial block: channel by channel, zeros behind cr (never reads past the row)
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             // {-a/2, -b} at 8; 3 = {c, opacity} -> {-c/2, opacity} at 16
             float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
             const uint2 qe = s_queue[(qh + (FULL ? rq : min(rq, nrows - 1))) & (QCAP - 1)];   // {walk index j, id | mask << 28}
-            if (qq == 1) v = make_float2(__uint_as_float(((uint32_t)(NS - 1 - (int)qe.x) << 4) | (qe.y >> RANK_BITS)), __uint_as_float(qe.y & RANK_MASK));
+            if (qq == 1) v = make_float2(__uint_as_float(((uint32_t)(NS - 1 - (int)qe.x) << 4) | (qe.y >> ID_BITS)), __uint_as_float(qe.y & ID_MASK));
             if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
             if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
             if (!FULL) {

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64, C == 32 ? FWD_WAVES32 : FWD_WAVES64) blend
     if (ns > 0) scan_reg = lst[min(lane, ns - 1)];
     auto consume_scan = [&]() {
         const int j = scanned + lane;
-        const bool cand = j < ns && ((scan_reg >> (RANK_BITS + quad)) & 1u) != 0;
+        const bool cand = j < ns && ((scan_reg >> (ID_BITS + quad)) & 1u) != 0;
         const uint64_t bal = ballot64(cand);
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg);
@@ -183,14 +183,14 @@ __global__ void __launch_bounds__(64, C == 32 ? FWD_WAVES32 : FWD_WAVES64) blend
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
             const int rq = min(lane >> 2, n - 1), qq = lane & 3;
-            const uint32_t gq = s_queue[(qh + ahead + rq) & (QCAP - 1)].y & RANK_MASK;
+            const uint32_t gq = s_queue[(qh + ahead + rq) & (QCAP - 1)].y & ID_MASK;
             rr.q = reinterpret_cast<const uint2*>(index_rec + gq)[qq];
         }
 #pragma unroll
         for (int k = 0; k < NK; k++) {
             const int e = lane + 64 * k;
             const int g = min(e / F4, n - 1), part = e % F4;
-            const size_t gid = (size_t)(s_queue[(qh + ahead + g) & (QCAP - 1)].y & RANK_MASK);
+            const size_t gid = (size_t)(s_queue[(qh + ahead + g) & (QCAP - 1)].y & ID_MASK);
             if constexpr (PARTIAL) {   // channel by channel, zeros behind cr (never reads past the row)
                 const float* row = features + gid * (size_t)cstride + 4 * part;
                 rr.f[k] = make_float4(4 * part + 0 < cr ? row[0] : 0.f, 4 * part + 1 < cr ? row[1] : 0.f,
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64, C == 32 ? FWD_WAVES32 : FWD_WAVES64) blend
             // 3 = {c, opacity} -> {-c/2, opacity}
             float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
             const uint2 qe = s_queue[(qh + min(rq, n - 1)) & (QCAP - 1)];   // {position, id | mask << 28}
-            if (qq == 1) v = make_float2(__uint_as_float(qe.x + 1u), __uint_as_float((qe.x << 4) | (qe.y >> RANK_BITS)));
+            if (qq == 1) v = make_float2(__uint_as_float(qe.x + 1u), __uint_as_float((qe.x << 4) | (qe.y >> ID_BITS)));
             if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
             if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
             if (rq >= n) {
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
     if (ns > 0) scan_reg = lst[min(lane, ns - 1)];
     auto consume_scan = [&]() {
         const int j = scanned + lane;
-        const bool cand = j < ns && ((scan_reg >> (RANK_BITS + quad)) & 1u) != 0;
+        const bool cand = j < ns && ((scan_reg >> (ID_BITS + quad)) & 1u) != 0;
         const uint64_t bal = ballot64(cand);
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (cand) s_queue[(qt + (int)below) & (QCAP - 1)] = make_uint2((uint32_t)j, scan_reg);
@@ -513,13 +513,13 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
             const int rq = min(lane >> 2, n - 1), qq = lane & 3;
-            const uint32_t gq = s_queue[(qh + rq) & (QCAP - 1)].y & RANK_MASK;
+            const uint32_t gq = s_queue[(qh + rq) & (QCAP - 1)].y & ID_MASK;
             curq = reinterpret_cast<const uint2*>(index_rec + gq)[qq];
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int g = min((lane >> 3) + 8 * k, n - 1), c = lane & 7;
-            const size_t gid = (size_t)(s_queue[(qh + g) & (QCAP - 1)].y & RANK_MASK);
+            const size_t gid = (size_t)(s_queue[(qh + g) & (QCAP - 1)].y & ID_MASK);
             float v = 0.f;
             if (c < C) v = features[gid * 3 + c];
             else if (EXTRA >= 1 && c == C) v = mask[gid];
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(64, 8) blend_fwd_wave_rgb_kernel(
             const int rq = lane >> 2, qq = lane & 3;
             float2 v = make_float2(__uint_as_float(curq.x), __uint_as_float(curq.y));
             const uint2 qe = s_queue[(qh + min(rq, n - 1)) & (QCAP - 1)];   // {position, id | mask << 28}
-            if (qq == 1) v = make_float2(__uint_as_float(qe.x + 1u), __uint_as_float((qe.x << 4) | (qe.y >> RANK_BITS)));
+            if (qq == 1) v = make_float2(__uint_as_float(qe.x + 1u), __uint_as_float((qe.x << 4) | (qe.y >> ID_BITS)));
             if (qq == 2) v = make_float2(-0.5f * v.x, -v.y);
             if (qq == 3) v = make_float2(-0.5f * v.x, v.y);
             if (rq >= n) {

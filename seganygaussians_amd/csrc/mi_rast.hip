@@ -17,7 +17,6 @@
 #include <string>
 
 #include "binning.h"
-#include "depth_sort.h"
 #include "knn_smooth.h"
 #include "knn.h"
 #include "blend_bwd.h"
@@ -76,55 +75,6 @@ struct Carver {
         return o;
     }
 };
-
-// Scratch of the depth ordering (depth_sort.h), carved from the geometry buffer's sort_temp field.
-struct DepthScratch {
-    int* cull_counter;    // first word: prefiltered-cull counter (live before the ordering starts)
-    uint2* pairs;         // [P] (depth bits, index), bucketed
-    uint2* pairs_tmp;     // [P] ping-pong for buckets too long for LDS
-    uint32_t* partial;    // [DS_MAX_WG][DS_NBK]
-    uint32_t* total;      // [DS_NBK]
-    uint2* ranges;        // [DS_NBK]
-    uint32_t* big_list;   // [1 + DS_NB]
-    int* out2;            // {V + culled == P, longest bucket}
-};
-size_t depth_sort_temp_bytes(int P, size_t* offs = nullptr)
-{
-    const size_t p = P > 0 ? (size_t)P : 1;
-    size_t o[8];
-    size_t at = 256;
-    auto take = [&](size_t n) {
-        const size_t r = at;
-        at = (at + n + 255) & ~(size_t)255;
-        return r;
-    };
-    o[0] = 0;
-    o[1] = take(p * sizeof(uint2));
-    o[2] = take(p * sizeof(uint2));
-    o[3] = take((size_t)DS_MAX_WG * DS_NBK * sizeof(uint32_t));
-    o[4] = take((size_t)DS_NBK * sizeof(uint32_t));
-    o[5] = take((size_t)DS_NBK * sizeof(uint2));
-    o[6] = take((size_t)(DS_NB + 2) * sizeof(uint32_t));
-    o[7] = take(16);
-    if (offs)
-        for (int i = 0; i < 8; i++) offs[i] = o[i];
-    return at;
-}
-DepthScratch depth_scratch(char* base, int P)
-{
-    size_t o[8];
-    depth_sort_temp_bytes(P, o);
-    DepthScratch d;
-    d.cull_counter = (int*)(base + o[0]);
-    d.pairs = (uint2*)(base + o[1]);
-    d.pairs_tmp = (uint2*)(base + o[2]);
-    d.partial = (uint32_t*)(base + o[3]);
-    d.total = (uint32_t*)(base + o[4]);
-    d.ranges = (uint2*)(base + o[5]);
-    d.big_list = (uint32_t*)(base + o[6]);
-    d.out2 = (int*)(base + o[7]);
-    return d;
-}
 
 // ---- host-side scratch for the num_rendered read-back: pinned words + two events per (host thread, device) ----
 constexpr int MAX_DEVICES = 64;
@@ -236,11 +186,9 @@ struct GeomPtrs {
     uint8_t* clamped;
     uint32_t* tiles_touched;
     uint32_t* depth_key;
-    BlendRec* index_rec;  // [P] {mean, id, radius, conic + opacity} in index order (written by the preprocess pass)
-    uint32_t* sorted_idx;
-    char* sort_temp;
+    BlendRec* index_rec;  // [P] {mean, id, radius, conic + opacity} in index order (written by the preprocess pass for visible Gaussians)
+    int* cull_counter;    // one word: Gaussians culled although `prefiltered` was set
     float* bwd_pack;  // [P,8] packed per-Gaussian field gradients (backward scratch)
-    BlendRec* rank_rec;  // [P] geometry records in depth-rank order (binning.h)
 };
 struct ImgPtrs {
     float* final_T;
@@ -256,8 +204,8 @@ struct ImgPtrs {
     uint32_t longest_run;   // host copy of the longest of those runs (forward only: read from the pinned words at the ev2 wait)
 };
 struct BinPtrs {
-    uint32_t* entries;   // per overlap: depth rank of the Gaussian, bucketed by tile (unsorted inside a tile)
-    uint32_t* scratch;   // ping-pong buffer for tiles too long for the LDS sort
+    uint2* entries;      // per overlap: {depth bits, Gaussian id | quadrant mask << 28}, bucketed by tile (unsorted inside a tile)
+    uint2* scratch;      // ping-pong buffer for tiles too long for the LDS sort
     uint32_t* blend_list;  // per tile at range.x, in depth order: Gaussian id | quadrant mask << 28 (binning.h: emit_blend_list); full
                            // lists: the low 28 bits are the reference's point_list
 };
@@ -276,10 +224,8 @@ GeomPtrs geom_from(char* base, int P)
     g.tiles_touched = (uint32_t*)(base + off[MI_GEOM_TILES_TOUCHED]);
     g.depth_key = (uint32_t*)(base + off[MI_GEOM_DEPTH_KEY]);
     g.index_rec = (BlendRec*)(base + off[MI_GEOM_INDEX_REC]);
-    g.sorted_idx = (uint32_t*)(base + off[MI_GEOM_SORTED_IDX]);
-    g.sort_temp = base + off[MI_GEOM_SORT_TEMP];
-        g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
-    g.rank_rec = (BlendRec*)(base + off[MI_GEOM_RANK_REC]);
+    g.cull_counter = (int*)(base + off[MI_GEOM_CULL_COUNTER]);
+    g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
     return g;
 }
 ImgPtrs img_from(char* base, int W, int H)
@@ -295,7 +241,7 @@ ImgPtrs img_from(char* base, int W, int H)
     m.tile_cursor = (uint32_t*)(base + off[MI_IMG_TILE_CURSOR]);
     m.num_rendered = (int*)(base + off[MI_IMG_NUM_RENDERED]);
     m.tile_nsurv = (uint32_t*)(base + off[MI_IMG_TILE_NSURV]);
-    m.run_bounds = reinterpret_cast<uint32_t*>(m.num_rendered + R_SLOTS * R_SLOT_STRIDE + 4);
+    m.run_bounds = reinterpret_cast<uint32_t*>(m.num_rendered + R_SLOTS * R_SLOT_STRIDE + NR_RUN_BOUNDS);
     m.longest_run = 0;
     return m;
 }
@@ -304,8 +250,8 @@ BinPtrs bin_from(char* base, int R)
     size_t off[MI_BIN_NFIELDS];
     mi_rast_binning_layout(R, off);
     BinPtrs b;
-    b.entries = (uint32_t*)(base + off[MI_BIN_ENTRIES]);
-    b.scratch = (uint32_t*)(base + off[MI_BIN_SCRATCH]);
+    b.entries = (uint2*)(base + off[MI_BIN_ENTRIES]);
+    b.scratch = (uint2*)(base + off[MI_BIN_SCRATCH]);
     b.blend_list = (uint32_t*)(base + off[MI_BIN_BLEND_LIST]);
     return b;
 }
@@ -399,11 +345,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (!img_base) return fail(MI_RAST_ERR_ALLOC, "image buffer callback returned NULL");
     img = img_from(img_base, W, H);
 
-    // the depth-sort temp area is not live yet: its first word is the prefiltered-cull counter
-    int* cull_counter = (int*)geom.sort_temp;
+    int* cull_counter = geom.cull_counter;
     if (prefiltered) HIP_TRY(hipMemsetAsync(cull_counter, 0, sizeof(int), stream));
     const int ntiles = (int)(vp.grid_x * vp.grid_y);
-    if (P >= (1 << RANK_BITS)) return fail(MI_RAST_ERR_INVALID, "more than 2^28 Gaussians");
+    if (P >= (1 << ID_BITS)) return fail(MI_RAST_ERR_INVALID, "more than 2^28 Gaussians");
     if (vp.grid_x > 1023u || vp.grid_y > 2047u)
         return fail(MI_RAST_ERR_INVALID, "image too large: more than 1023 tiles across or 2047 tiles down");
     // images with more tiles than one launch of the count / emit passes has LDS counters for are walked in bands of tile rows
@@ -436,102 +381,56 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#ifdef MI_RAST_PROFILING
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#endif
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)run_bounds_from_walks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
-            HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        DS_NBK * (int)sizeof(uint32_t)));
-            HIP_TRY(hipFuncSetAttribute((const void*)depth_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        DS_NBK * (int)sizeof(uint32_t)));
             g_attr_set[dev].store(true, std::memory_order_release);
         }
     }
-    // R is known after the preprocess pass; the first kernel of the depth sort stores its partial sums into the host's pinned
-    // buffer, and the host reads them while the depth sort and the counting passes run.
+    // R is known after the preprocess pass; the count pass stores its partial sums into the host's pinned
+    // buffer, and the host reads them while the scans run.
     if (!g_host_sync.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host buffer / event");
-    {
-        StageTimer t(stream, MI_STAGE_DEPTH_SORT);
-        // depth ordering -> sorted_idx[rank] and the per-rank geometry records (depth_sort.h): 6 launches
-        const DepthScratch ds = depth_scratch(geom.sort_temp, P);
-        int nwg_d = depth_workgroups(P);
-#ifdef MI_RAST_PROFILING
-        if (ablate_env("MI_RAST_NWG_D") > 0) nwg_d = std::min(nwg_d, ablate_env("MI_RAST_NWG_D"));
-#endif
-        int idx_bits = 1;
-        while ((1ll << idx_bits) < (long long)P) idx_bits++;
-        const int idx_passes = (idx_bits + 7) / 8;
-        hipLaunchKernelGGL(depth_bucket_kernel<false>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
-                           geom.depth_key, ds.partial, (const uint2*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (BlendRec*)nullptr,
-                           (const int*)img.num_rendered, g_host_sync.pinned_dev);
-        HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
-        hipLaunchKernelGGL(scan_partials_kernel, dim3((DS_NBK + 63) / 64), dim3(1024), 0, stream, DS_NBK, nwg_d, ds.partial, ds.total);
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), (DS_NBK + 1) * sizeof(uint32_t), stream, DS_NBK, ds.total, ds.ranges, ds.out2,
-                           (uint32_t)DS_WAVE, DS_NB, ds.big_list);
-        hipLaunchKernelGGL(depth_bucket_kernel<true>, dim3(nwg_d), dim3(1024), DS_NBK * sizeof(uint32_t), stream, P,
-                           geom.depth_key, ds.partial, ds.ranges, ds.pairs, geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
-        hipLaunchKernelGGL(depth_bucket_sort_wave_kernel, dim3((DS_NB + 3) / 4), dim3(256), 0, stream, ds.ranges, ds.pairs,
-                           geom.index_rec, geom.sorted_idx, geom.rank_rec);
-        hipLaunchKernelGGL((depth_bucket_sort_kernel<DS_WAVE, DS_LARGE, true>), dim3(2048), dim3(256), 0, stream, ds.ranges,
-                           ds.big_list, ds.pairs, ds.pairs_tmp, idx_passes, geom.index_rec,
-                           geom.sorted_idx, geom.rank_rec, (const int*)img.num_rendered);
-    }
-    STAGE_CHECK("depth sort");
     // Full lists (the reference's point_list and full-list positions) are materialised on request -- the reference's
     // `debug` flag or MI_RAST_FULL_LISTS -- ; otherwise only the overlaps that pass the cull are listed.
     const bool nocull = (flags & MI_RAST_NO_CULL) != 0;
     const bool full = debug != 0 || nocull || (flags & MI_RAST_FULL_LISTS) != 0;
-    // full lists: <= 256 workgroups of 1024 threads; lean lists: workgroups of BIN_LEAN_THREADS (binning.h; MI_RAST_BIN_NT in the
-    // profiling build), twice as many slices when they are 512 threads wide
-#ifdef MI_RAST_PROFILING
-    const int lean_nt = knob("MI_RAST_BIN_NT", BIN_LEAN_THREADS) == 512 ? 512 : 1024;
-#else
-    constexpr int lean_nt = BIN_LEAN_THREADS;
-#endif
-    int nwg = full ? bin_workgroups(P) : bin_lean_workgroups(P, lean_nt);
+    // <= 256 workgroups of 1024 threads, each a slice of the Gaussians (64-index chunks dealt round robin)
+    int nwg = bin_workgroups(P);
 #ifdef MI_RAST_PROFILING
     if (ablate_env("MI_RAST_NWG") > 0) nwg = std::min(nwg, ablate_env("MI_RAST_NWG"));
 #endif
     const size_t band_tiles = (size_t)band_rows * vp.grid_x;
     const size_t bin_lds = ((size_t)((band_tiles + 3) & ~(size_t)3) + 3 * 1024 + 16) * sizeof(uint32_t);
     {
-        // count pass over rank slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
+        // count pass over slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
         StageTimer t(stream, MI_STAGE_TILE_SCAN);
         const size_t cnt_lds = (size_t)(band_rows + 1) * count_grid_stride(vp.grid_x) * sizeof(int);
         for (uint32_t b = 0; b < nbands; b++) {
             const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
             if (full)
-                hipLaunchKernelGGL(bin_count_kernel, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.rank_rec,
-                                   img.tile_count, vp.grid_x, vp.grid_y, by0, by1);
-#ifdef MI_RAST_PROFILING
-            else if (lean_nt == 512)
-                hipLaunchKernelGGL((bin_spans_kernel<false, 512>), dim3(nwg), dim3(512),
-                                   ((((size_t)(by1 - by0) * count_grid_stride(vp.grid_x) + 3) & ~(size_t)3) + span_lds_words(512)) * sizeof(uint32_t),
-                                   stream, P, geom.rank_rec, img.tile_count, (const uint2*)nullptr, (uint32_t*)nullptr, vp.grid_x,
-                                   vp.grid_y, by0, by1, g_ablate_fwd);
-#endif
+                hipLaunchKernelGGL(bin_count_kernel, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.index_rec, geom.depth_key,
+                                   img.tile_count, vp.grid_x, vp.grid_y, by0, by1, (const int*)img.num_rendered,
+                                   b == 0 ? g_host_sync.pinned_dev : (int*)nullptr);
             else
-                hipLaunchKernelGGL((bin_spans_kernel<false, 1024>), dim3(nwg), dim3(1024),
-                                   ((((size_t)(by1 - by0) * count_grid_stride(vp.grid_x) + 3) & ~(size_t)3) + span_lds_words(1024)) * sizeof(uint32_t),
-                                   stream, P, geom.rank_rec, img.tile_count, (const uint2*)nullptr, (uint32_t*)nullptr, vp.grid_x,
-                                   vp.grid_y, by0, by1, g_ablate_fwd);
+                hipLaunchKernelGGL(bin_spans_kernel<false>, dim3(nwg), dim3(1024),
+                                   span_lds_bytes((size_t)(by1 - by0) * count_grid_stride(vp.grid_x)), stream, P, geom.index_rec,
+                                   geom.depth_key, img.tile_count, (const uint2*)nullptr, (uint2*)nullptr, vp.grid_x, vp.grid_y, by0, by1,
+                                   (const int*)img.num_rendered, b == 0 ? g_host_sync.pinned_dev : (int*)nullptr, g_ablate_fwd);
         }
+        HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
         // (one launch for both scans -- every workgroup scans its tiles over the slices, the last one to finish scans the totals
-        // behind a device-scope counter and agent-scope fences -- was built and measured in round 4: depth order 0.079 -> 0.086 ms,
-        // tile scan 0.058 -> 0.060 ms on cfg3; the fences and the serial tail inside the kernel cost more than the launch they save)
+        // behind a device-scope counter and agent-scope fences -- was built and measured in round 4: tile scan 0.058 -> 0.060 ms
+        // on cfg3; the fences and the serial tail inside the kernel cost more than the launch they save)
         hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                            img.tile_count, img.tile_cursor);
         const uint32_t run_cap = !(flags & MI_RAST_EQUAL_RUNS) ? (uint32_t)std::max(0, knob("MI_RAST_RUN_CAP", RUN_MODEL_CAP)) : 0u;
         const uint32_t run_fix = (uint32_t)std::max(0, knob("MI_RAST_RUN_FIX", RUN_MODEL_FIX));
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024),
                            ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor,
-                           img.ranges, img.num_rendered + R_SLOTS * R_SLOT_STRIDE, 0xFFFFFFFFu, 0, (uint32_t*)nullptr,
+                           img.ranges, img.num_rendered + R_SLOTS * R_SLOT_STRIDE, (const int*)img.num_rendered,
                            g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds, run_cap, run_fix);
     }
     STAGE_CHECK("tile scan");
@@ -552,33 +451,27 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     bin = bin_from(bin_base, R);
     const bool verify = !full && (flags & MI_RAST_VERIFY_LISTS) != 0;
     if (R > 0) {
-        if (verify) HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint32_t), stream));
+        if (verify) HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint2), stream));
         {
             StageTimer t(stream, MI_STAGE_EMIT);
             const size_t emit_lds = bin_lds + 8 * 1024 * sizeof(uint32_t);
             for (uint32_t b = 0; b < nbands; b++) {
                 const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
                 if (nocull)
-                    hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
+                    hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.index_rec, geom.depth_key,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
                 else if (full)
-                    hipLaunchKernelGGL(bin_ranks_kernel<false>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.rank_rec,
+                    hipLaunchKernelGGL(bin_ranks_kernel<false>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.index_rec, geom.depth_key,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
-#ifdef MI_RAST_PROFILING
-                else if (lean_nt == 512)
-                    hipLaunchKernelGGL((bin_spans_kernel<true, 512>), dim3(nwg), dim3(512),
-                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + span_lds_words(512)) * sizeof(uint32_t), stream, P,
-                                       geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1, g_ablate_fwd);
-#endif
                 else
-                    hipLaunchKernelGGL((bin_spans_kernel<true, 1024>), dim3(nwg), dim3(1024),
-                                       ((((size_t)(by1 - by0) * vp.grid_x + 3) & ~(size_t)3) + span_lds_words(1024)) * sizeof(uint32_t), stream, P,
-                                       geom.rank_rec, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1, g_ablate_fwd);
+                    hipLaunchKernelGGL(bin_spans_kernel<true>, dim3(nwg), dim3(1024), span_lds_bytes((size_t)(by1 - by0) * vp.grid_x), stream, P,
+                                       geom.index_rec, geom.depth_key, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1,
+                                       (const int*)nullptr, (int*)nullptr, g_ablate_fwd);
             }
         }
-        STAGE_CHECK("emit ranks");
+        STAGE_CHECK("emit entries");
         if (verify) {   // debugging aid: synchronous
-            uint32_t* ctr = reinterpret_cast<uint32_t*>(img.num_rendered + R_SLOTS * R_SLOT_STRIDE + 2);
+            uint32_t* ctr = reinterpret_cast<uint32_t*>(img.num_rendered + R_SLOTS * R_SLOT_STRIDE + NR_VERIFY);
             HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(uint32_t), stream));
             hipLaunchKernelGGL(verify_entries_kernel, dim3(ntiles), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges, bin.entries, ctr);
             uint32_t unwritten = 0;
@@ -588,29 +481,24 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                 return fail(MI_RAST_ERR_HIP, "internal error: " + std::to_string(unwritten) + " list slots were counted but not emitted "
                                              "(count / emit passes of bin_spans_kernel disagree)");
         }
-        int rank_bits = 1;
-        while ((1ll << rank_bits) < (long long)P) rank_bits++;
-        int passes = (rank_bits + 7) / 8;
-#ifdef MI_RAST_PROFILING
-        if (g_ablate_fwd & 256) passes = 0;  // timing experiment: skip the radix passes (wrong order)
-#endif
+        const int* key_bits = img.num_rendered + R_SLOTS * R_SLOT_STRIDE + NR_KEY_BITS;
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
-            // three list-length classes (256 threads + 20 KB of LDS, 1024 threads + 64 KB, 1024 threads + 112 KB); a class is launched only if
+            // three list-length classes (256 threads + 36 KB of LDS, 1024 threads + 112 KB, 1024 threads + 144 KB); a class is launched only if
             // some tile needs it.  The longest list was copied to the host right after the range scan, which
             // finished before the emit pass above even started: this wait does not stall the queue.
 #define LAUNCH_TILE_SORT(LO, CAP, FB, NT)                                                                                 \
     hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges,  \
-                       bin.entries, bin.scratch, geom.sorted_idx, passes, bin.blend_list)
+                       bin.entries, bin.scratch, key_bits, bin.blend_list)
             LAUNCH_TILE_SORT(0, 2048, false, 256);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
-            img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + 4, (uint32_t)ntiles);
+            img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + NR_RUN_BOUNDS, (uint32_t)ntiles);
             // lean lists: the counts are the lists' exact lengths (bin_spans_kernel), their sum a lower bound of R
-            if (full ? g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] != R : g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE] > R)
+            if (full ? g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + NR_TOTAL] != R : g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + NR_TOTAL] > R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
-            const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + 1];
+            const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + NR_LONGEST];
             if (max_tile_count > 2048) LAUNCH_TILE_SORT(2048, 6144, false, 1024);
-            if (max_tile_count > 6144) LAUNCH_TILE_SORT(6144, 12288, true, 1024);
+            if (max_tile_count > 6144) LAUNCH_TILE_SORT(6144, 8192, true, 1024);
 #undef LAUNCH_TILE_SORT
         }
         STAGE_CHECK("tile sort");
@@ -618,7 +506,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         // no overlap at all (every tile's range is {0, 0}: the blend kernels read no list).  The range scan stores {total, longest list} into this thread's pinned words: never return while that store can still
         // land (the next forward of this thread, on another stream, would read them)
         HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
-        img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + 4, (uint32_t)ntiles);
+        img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + NR_RUN_BOUNDS, (uint32_t)ntiles);
     }
     return MI_RAST_OK;
 }
@@ -986,10 +874,8 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_TILES_TOUCHED] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_DEPTH_KEY] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_INDEX_REC] = c.take(p * sizeof(BlendRec));
-    off[MI_GEOM_SORTED_IDX] = c.take(p * sizeof(uint32_t));
-    off[MI_GEOM_SORT_TEMP] = c.take(depth_sort_temp_bytes(P) + 16);
+    off[MI_GEOM_CULL_COUNTER] = c.take(16);
     off[MI_GEOM_BWD_PACK] = c.take(bwd_pack_bytes((int)p));  // + the backward's work-queue counters, one set per channel block
-    off[MI_GEOM_RANK_REC] = c.take(p * sizeof(BlendRec));
     return c.off;
 }
 size_t mi_rast_image_layout(int width, int height, size_t* off)
@@ -1002,11 +888,7 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     off[MI_IMG_RANGES] = c.take((tiles ? tiles : 1) * sizeof(uint2));
     off[MI_IMG_TILE_CONSUMED] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     // tile_count holds partial[slice][tile] of the count / emit passes (binning.h); tile_cursor the tile totals
-#ifdef MI_RAST_PROFILING
-    constexpr int max_slices = BIN_LEAN_MAX_WG;   // (MI_RAST_BIN_NT=512: twice the rank slices)
-#else
     constexpr int max_slices = BIN_MAX_WG;
-#endif
     off[MI_IMG_TILE_COUNT] = c.take((size_t)max_slices * (tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_NUM_RENDERED] = c.take((R_SLOTS * R_SLOT_STRIDE + 16) * sizeof(int));  // R partial sums, then {R, longest list}, then the nine run boundaries
@@ -1017,8 +899,8 @@ size_t mi_rast_binning_layout(int R, size_t* off)
 {
     const size_t r = R > 0 ? (size_t)R : 1;
     Carver c;
-    off[MI_BIN_ENTRIES] = c.take(r * sizeof(uint32_t));
-    off[MI_BIN_SCRATCH] = c.take(r * sizeof(uint32_t));
+    off[MI_BIN_ENTRIES] = c.take(r * sizeof(uint2));
+    off[MI_BIN_SCRATCH] = c.take(r * sizeof(uint2));
     off[MI_BIN_BLEND_LIST] = c.take(r * sizeof(uint32_t));
     return c.off;
 }

@@ -174,8 +174,7 @@ class GpuRun:
                     rgb=self._view(self.geom, off["rgb"], 3 * P, np.float32),
                     clamped=self._view(self.geom, off["clamped"], 3 * P, np.uint8),
                     tiles_touched=self._view(self.geom, off["tiles_touched"], P, np.uint32),
-                    depth_key=self._view(self.geom, off["depth_key"], P, np.uint32),
-                    sorted_idx=self._view(self.geom, off["sorted_idx"], P, np.uint32))
+                    depth_key=self._view(self.geom, off["depth_key"], P, np.uint32))
 
     def bin_fields(self):
         """point_list: the low 28 bits of the blend list -- with full lists the reference's sorted id list, bit for bit."""

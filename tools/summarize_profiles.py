@@ -31,18 +31,56 @@ def short(n):
     return n[:90]
 
 
-STAGE_OF = {"blend_bwd_wave_kernel": "blend_bwd", "blend_bwd32_mfma_kernel": "blend_bwd", "blend_bwd_mfma_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "blend_fwd_x3_kernel": "blend_fwd", "blend_fwd_wave_kernel": "blend_fwd", "blend_fwd_wave_rgb_kernel": "blend_fwd",
-            "preprocess_fwd_kernel": "preprocess", "bin_spans_kernel<true>": "emit", "bin_spans_kernel<false>": "tile_scan", "bin_ranks_kernel<true, false>": "emit", "bin_ranks_kernel<true, false, false>": "emit",
-            "tile_sort_kernel": "tile_sort",
-            "bin_ranks_kernel<false, false>": "tile_scan", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
-            "depth_bucket_kernel<false>": "depth_sort", "depth_bucket_kernel<true>": "depth_sort",
-            "depth_bucket_sort_kernel": "depth_sort", "depth_bucket_sort_wave_kernel": "depth_sort", "geometry_bwd_kernel": "geom_bwd"}
+# kernel -> stage of bench.py's roofline.stages.  Matched on the kernel's BASE name, plus its first template argument where one
+# kernel serves two stages (bin_spans_kernel<EMIT, ...>): round 5 keyed this table on full instance names, the instances grew a second
+# argument, and the emit / count kernels silently dropped out of traffic_*.json.  A kernel of the library that holds more than 1 % of
+# the trace and maps to no stage is an ERROR now (stage_of(..., strict=True)).
+STAGE_BY_BASE = {"blend_bwd_wave_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd",
+                 "blend_fwd_kernel": "blend_fwd", "blend_fwd_x3_kernel": "blend_fwd", "blend_fwd_wave_kernel": "blend_fwd", "blend_fwd_wave_rgb_kernel": "blend_fwd",
+                 "run_bounds_from_walks_kernel": "blend_fwd",
+                 "preprocess_fwd_kernel": "preprocess", "bin_count_kernel": "tile_scan", "bin_ranks_kernel": "emit", "verify_entries_kernel": "emit",
+                 "tile_sort_kernel": "tile_sort", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
+                 "geometry_bwd_kernel": "geom_bwd", "unpack_mask_kernel": "geom_bwd"}
+STAGE_BY_FIRST_ARG = {"bin_spans_kernel": {"true": "emit", "false": "tile_scan"}}
+
+
+def base_and_args(name):
+    """'void mirast::bin_spans_kernel<true, 1024>(int, ...)' -> ('bin_spans_kernel', ['true', '1024'], True)"""
+    n = re.sub(r"\(.*", "", name).replace("void ", "").strip()
+    ours = n.startswith("mirast::")
+    n = n.replace("mirast::", "")
+    m = re.match(r"([A-Za-z_0-9:]+)(?:<(.*)>)?$", n)
+    if not m:
+        return n, [], ours
+    return m.group(1), [a.strip() for a in (m.group(2) or "").split(",") if a.strip()], ours
+
+
+def stage_of(name):
+    base, args, _ = base_and_args(name)
+    if base in STAGE_BY_FIRST_ARG:
+        return STAGE_BY_FIRST_ARG[base].get(args[0] if args else "")
+    return STAGE_BY_BASE.get(base)
+
+
+def pmc_key(name):
+    """Row key of the PMC tables: the base name; the first template argument kept where it selects the stage."""
+    base, args, _ = base_and_args(name)
+    return f"{base}<{args[0]}>" if base in STAGE_BY_FIRST_ARG and args else base
+
 
 rows = list(csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))))
 agg = {}
 for r in rows:
     a = agg.setdefault(short(r["Name"]), [0, 0]); a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
 tot = sum(v[1] for v in agg.values())
+unmapped = {}
+for r in rows:
+    base, args, ours = base_and_args(r["Name"])
+    if ours and stage_of(r["Name"]) is None and not base.startswith("knn") and not base.startswith("contrastive"):
+        unmapped[base] = unmapped.get(base, 0) + int(r["TotalDurationNs"])
+bad = {k: v for k, v in unmapped.items() if v > 0.01 * tot}
+if bad:
+    sys.exit(f"summarize_profiles: kernels with > 1 % of the trace map to no stage of bench.py: {bad} -- extend STAGE_BY_BASE / STAGE_BY_FIRST_ARG")
 bench_line = open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1]
 stamp = (json.loads(bench_line).get("roofline") or {}).get("library")
 with open(os.path.join(dst, f"{tag}_kernel_stats{sfx}.md"), "w") as f:
@@ -65,15 +103,13 @@ def pmc(name):
     if not os.path.exists(path):
         return out
     for r in csv.DictReader(open(path)):
-        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("mirast::", "")
-        if not (k.startswith("bin_spans_kernel") or k.startswith("depth_bucket_kernel")):
-            k = re.sub(r"<.*", "", k)
-        out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        out[pmc_key(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
 
 fetch, write = pmc("fetch"), pmc("write")
 traffic = {}
+untracked = {}   # kernels of the PMC passes that belong to no stage (torch fills, knn, ...): listed, not summed
 with open(os.path.join(dst, f"{tag}_pmc{sfx}.md"), "w") as f:
     f.write(f"# rocprofv3 PMC passes ({tag}, {cfg}, library {stamp})\n\nSeparate passes per counter group (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, two SQ groups), "
             "`--kernel-trace` only, same bench command. FETCH_SIZE / WRITE_SIZE are in KiB per dispatch (averaged over the "
@@ -86,10 +122,12 @@ with open(os.path.join(dst, f"{tag}_pmc{sfx}.md"), "w") as f:
         fa, wa = sum(fs) / len(fs), sum(ws) / len(ws)
         corr, raw = (2 * fa + wa) * 1024, (fa + wa) * 1024
         f.write(f"| `{k}` | {fa:.0f} | {wa:.0f} | {corr/1e6:.1f} | {raw/1e6:.1f} |\n")
-        st = STAGE_OF.get(k)
+        st = stage_of(k)
         if st:
             t = traffic.setdefault(st, {"bytes_per_launch": 0.0, "kernels": []})
             t["bytes_per_launch"] += corr; t["kernels"].append(k)
+        elif corr > 0:
+            untracked[k] = corr
     for name in ("sq1", "sq2"):
         p = pmc(name)
         if not p: continue
@@ -106,7 +144,7 @@ alu = {}
 sq1, sq2 = pmc("sq1"), pmc("sq2")
 avg = lambda d, k: (sum(d[k]) / len(d[k])) if k in d and d[k] else None
 for k in set(sq1) & set(sq2):
-    st = STAGE_OF.get(k)
+    st = stage_of(k)
     gui, mf, va = avg(sq2[k], "GRBM_GUI_ACTIVE"), avg(sq2[k], "SQ_VALU_MFMA_BUSY_CYCLES"), avg(sq1[k], "SQ_ACTIVE_INST_VALU")
     if not st or not gui:
         continue
@@ -119,6 +157,8 @@ alu["_source"] = f"profiles/{tag}_pmc{sfx}.md"
 json.dump(alu, open(os.path.join(dst, f"alu_{cfg}.json"), "w"), indent=1)
 for st in traffic.values():
     st["bytes_per_launch"] = round(st["bytes_per_launch"])
+traffic["_sum_of_stages"] = sum(st["bytes_per_launch"] for st in traffic.values())   # = the sum over every mapped kernel of the PMC table above
+traffic["_untracked_kernels"] = {k: round(v) for k, v in untracked.items()}
 traffic["_source"] = f"profiles/{tag}_pmc{sfx}.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note)"
 traffic["_stamp"] = stamp
 json.dump(traffic, open(os.path.join(dst, f"traffic_{cfg}.json"), "w"), indent=1)
