@@ -14,7 +14,6 @@ LIB_PATH = os.path.join(_HERE, "libmi_rast.so")
 PROF_LIB_PATH = os.path.join(_HERE, "libmi_rast_prof.so")
 SRC_DIR = os.path.join(_HERE, "csrc")
 SOURCES = ["mi_rast.hip", "common.h", "cull.h", "geometry.h", "binning.h", "knn_smooth.h", "knn.h", "blend_fwd.h", "blend_fwd_split.h", "blend_fwd_wave.h", "blend_fwd_x3.h", "blend_bwd.h", "blend_bwd_shared.h", "blend_bwd_wave.h", "contrastive.h"]
-LAB_BWD = os.path.join(os.path.dirname(_HERE), "tools", "experiments", "blend_bwd_wave_lab.h")   # profiling build only (mi_rast.hip)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "mi_rast.h")
 HEADERS = [os.path.join(os.path.dirname(_HERE), "include", h) for h in ("mi_rast.h", "mi_knn.h", "mi_knn_smooth.h", "mi_contrastive.h")]
 
@@ -33,8 +32,6 @@ def source_hash(extra_flags=()) -> str:
     for path in sorted([os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR) if f.endswith((".h", ".hip"))] + HEADERS):
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
-    if "-DMI_RAST_PROFILING" in extra_flags:   # the profiling build compiles the lab copy of the backward kernel in place of the product header
-        h.update(open(LAB_BWD, "rb").read())
     h.update(" ".join(list(HIPCC_FLAGS) + list(extra_flags)).encode())
     return h.hexdigest()[:12]
 
@@ -55,7 +52,7 @@ def is_stale(lib_path: str = None) -> bool:
     if not os.path.exists(lib_path):
         return True
     t = os.path.getmtime(lib_path)
-    deps = [os.path.join(SRC_DIR, s) for s in SOURCES] + HEADERS + ([LAB_BWD] if lib_path == PROF_LIB_PATH else [])
+    deps = [os.path.join(SRC_DIR, s) for s in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 

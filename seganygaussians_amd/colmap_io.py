@@ -158,6 +158,8 @@ def image_size_of(path: str) -> tuple:
     with open(path, "rb") as f:
         head = f.read(26)
         if head[:8] == b"\x89PNG\r\n\x1a\n":
+            if len(head) < 24:
+                raise ValueError(f"{path}: truncated PNG header")
             return struct.unpack(">II", head[16:24])
         if head[:2] != b"\xff\xd8":
             raise ValueError(f"{path}: neither PNG nor JPEG")
@@ -172,12 +174,19 @@ def image_size_of(path: str) -> tuple:
                 raise ValueError(f"{path}: no JPEG frame header")
             m = b[0]
             if 0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):   # SOFn
-                f.read(3)
-                h, w = struct.unpack(">HH", f.read(4))
+                seg = f.read(7)
+                if len(seg) < 7:   # truncated file
+                    raise ValueError(f"{path}: no JPEG frame header")
+                h, w = struct.unpack(">HH", seg[3:7])
                 return w, h
             if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7:
                 continue
-            f.seek(struct.unpack(">H", f.read(2))[0] - 2, 1)
+            if m in (0xD9, 0xDA):   # end of image / start of scan before any frame header
+                raise ValueError(f"{path}: no JPEG frame header")
+            ln = f.read(2)
+            if len(ln) < 2 or struct.unpack(">H", ln)[0] < 2:
+                raise ValueError(f"{path}: no JPEG frame header")
+            f.seek(struct.unpack(">H", ln)[0] - 2, 1)
 
 
 def to_camera(c: ColmapCamera, resolution: float = -1, image_size: Optional[tuple] = None) -> scenes.Camera:

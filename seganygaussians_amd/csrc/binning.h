@@ -27,6 +27,8 @@
 // the 64-bit keys are never materialised.
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 #include "cull.h"
 
@@ -39,6 +41,28 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
         const uint32_t t = __shfl_up(v, o, 64);
         if (lane >= o) v += t;
     }
+    return v;
+}
+
+// The same scan on the VALU alone (seven DPP moves: row_shr 1 / 2 / 3, row_shr 4 and 8 under bank masks, row_bcast 15 and 31
+// under row masks -- the sequence of AMD's GCN3 cross-lane note) instead of six trips through the LDS crossbar (__shfl_up is
+// ds_bpermute): for the count / emit passes, whose waves run two scans per window.  MAX: running maximum instead of sum.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);   // lanes without a source / masked off: 0
+}
+template <bool MAX = false>
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t v0)
+{
+    auto op = [](uint32_t a, uint32_t b) { return MAX ? max(a, b) : a + b; };
+    uint32_t v = op(v0, dpp_or_zero<0x111, 0xF, 0xF>(v0));   // row_shr:1
+    v = op(v, dpp_or_zero<0x112, 0xF, 0xF>(v0));             // row_shr:2
+    v = op(v, dpp_or_zero<0x113, 0xF, 0xF>(v0));             // row_shr:3  -> windows of four
+    v = op(v, dpp_or_zero<0x114, 0xF, 0xE>(v));              // row_shr:4, lanes 4 .. 15 of a row -> windows of eight
+    v = op(v, dpp_or_zero<0x118, 0xF, 0xC>(v));              // row_shr:8, lanes 8 .. 15 -> the row's prefix
+    v = op(v, dpp_or_zero<0x142, 0xA, 0xF>(v));              // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_or_zero<0x143, 0xC, 0xF>(v));              // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -260,6 +284,55 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
             host_out[NR_LONGEST] = (int)s_maxcount;
         }
     }
+}
+
+// ---- content fingerprints (mi_rast_fingerprint, include/mi_rast.h) ---------------------------------------------------------
+constexpr int MI_FP_MAX = 8;      // arrays per call
+constexpr int FP_BLOCKS = 128;    // partial sums per array (summed by the host)
+struct FingerprintArgs {
+    const uint32_t* ptr[MI_FP_MAX];
+    unsigned long long words[MI_FP_MAX];
+};
+// blockIdx.y = array; every word is hashed together with its position (murmur3's finaliser) and the hashes are summed: order of
+// summation does not matter, order of the words does.
+__global__ void __launch_bounds__(256) fingerprint_kernel(FingerprintArgs a, unsigned long long* __restrict__ out)
+{
+    const int k = blockIdx.y;
+    const uint32_t* p = a.ptr[k];
+    const unsigned long long n = a.words[k];
+    unsigned long long sum = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)FP_BLOCKS * 256ull) {
+        uint32_t x = p[i] ^ ((uint32_t)i * 0x9E3779B1u + (uint32_t)(i >> 32));
+        x ^= x >> 16;
+        x *= 0x85EBCA6Bu;
+        x ^= x >> 13;
+        x *= 0xC2B2AE35u;
+        x ^= x >> 16;
+        sum += (unsigned long long)x * 0x9E3779B97F4A7C15ull + i;
+    }
+    __shared__ unsigned long long s_part[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) out[k * FP_BLOCKS + blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// mi_rast_forward_reuse (include/mi_rast.h): a fresh image buffer takes over what the binning stages of an earlier forward of the same
+// geometry and camera left in theirs -- ranges, {R, longest list, key bits}, the XCD run boundaries -- and gets the blend kernels'
+// per-tile walk counters zeroed, as tile_ranges_kernel leaves them.
+__global__ void __launch_bounds__(256) reuse_image_state_kernel(uint32_t ntiles, const uint2* __restrict__ src_ranges,
+                                                                const int* __restrict__ src_words, uint2* __restrict__ ranges,
+                                                                int* __restrict__ words, uint32_t* __restrict__ zero_a,
+                                                                uint32_t* __restrict__ zero_b)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < ntiles) {
+        ranges[t] = src_ranges[t];
+        zero_a[t] = 0u;
+        zero_b[t] = 0u;
+    }
+    if (t < 16u) words[t] = src_words[t];   // {R, longest list, -, key bits, run boundaries}: the 16 words behind the R partial sums
 }
 
 // Run boundaries of the BACKWARD blend from what the forward walked (tile_nsurv: the entries of a tile's list the forward reached
@@ -509,19 +582,39 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
 // on cfg3, ~1 us per phase whatever it computed).  Hand-offs between the lanes of a wave go through wave-private LDS words;
 // LDS operations of one wave execute in program order, the wavefront fences keep the compiler from reordering them.
 // Measured on cfg3: 2.27 M (Gaussian, row) items, 2.93 M entries.
-constexpr int BW_WORDS = 64 * 14;  // LDS words per wave: prefix, rect, radius, depth bits, mean (2), conic + opacity (4); emit: span prefix, two bands' columns, span origin
+constexpr int BW_WORDS = 64 * 16;  // LDS words per wave: prefix, rect, depth bits, owner scratch, two float4 of span constants + mean; emit: span prefix, two bands' columns, span origin
 __host__ __device__ constexpr size_t span_lds_bytes(size_t head_words) { return (((head_words + 3) & ~(size_t)3) + 4 + 16 * BW_WORDS) * sizeof(uint32_t); }
 
-// first slot g of a wave-private inclusive prefix (64 words) with pre[g] > k; k < pre[63]
-__device__ __forceinline__ int wave_owner(const uint32_t* pre, uint32_t k)
+// Hand-off point between the lanes of ONE wave through LDS: LDS operations of a wave execute in program order, so no wait is needed --
+// but the compiler must neither move LDS accesses across this point nor forward a lane's own store to its later load (another
+// lane may have stored there in between): a full fence at wavefront scope (no instruction) plus a scheduling barrier.
+__device__ __forceinline__ void wave_lds_fence()
 {
-    int g = 0;
-#pragma unroll
-    for (int step = 32; step >= 1; step >>= 1)
-        if (pre[g + step - 1] <= k) g += step;
-    return g;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// Owner of item k = base + lane of a balanced walk: the lane o with excl[o] <= k < incl[o] (excl / incl: the lanes' exclusive /
+// inclusive prefix of item counts; k < total).  The lane that owns position `base` is found by a ballot; every lane whose items
+// START inside the window (base, base + 64) leaves its number at the start position in a wave-private LDS word, and a running
+// maximum over the positions (lane numbers ascend with the prefix) spreads it to the positions behind: one LDS round trip and a
+// DPP scan instead of a six-step binary search through LDS.
+__device__ __forceinline__ uint32_t wave_owner(uint32_t* scratch /* [64] wave-private */, uint32_t excl, uint32_t incl, uint32_t base, int lane)
+{
+    const uint64_t first = ballot64(excl <= base && base < incl);
+    const uint32_t owner0 = (uint32_t)__builtin_ctzll(first | (1ull << 63));
+    // Lanes exchange words through LDS here: FULL fences (acquire + release, wavefront scope).  With release fences alone the
+    // compiler forwards a lane's own `scratch[lane] = 0` to its own load of scratch[lane] -- another lane's store to that word is a
+    // data race it may assume away -- and the owners come out wrong (round 6: a memory fault in the emit pass; tools/
+    // wave_prims_probe.hip checks this function against a serial search on the GPU).
+    scratch[lane] = 0u;
+    wave_lds_fence();
+    if (incl > excl && excl > base && excl - base < 64u) scratch[excl - base] = (uint32_t)lane;
+    wave_lds_fence();
+    const uint32_t here = scratch[lane];
+    wave_lds_fence();
+    return max(wave_inclusive_scan_dpp<true>(here), owner0);
+}
 
 template <bool EMIT>
 __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* __restrict__ index_rec,
@@ -547,14 +640,14 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
     uint32_t* wb = s_dyn + head + 4 + wave * BW_WORDS;
     uint32_t* w_pre = wb;              // inclusive prefix of the lanes' row counts
     uint32_t* w_rect = wb + 64;        // clip columns x0 | x1 << 10, first row << 21
-    uint32_t* w_rad = wb + 128;        // radius (the margin of tau needs it)
-    uint32_t* w_key = wb + 192;        // depth bits
-    float2* w_xy = reinterpret_cast<float2*>(wb + 256);
-    float4* w_co = reinterpret_cast<float4*>(wb + 384);
-    uint32_t* w_tpre = wb + 640;       // EMIT, per span of the window: inclusive prefix of the spans' widths
-    uint32_t* w_q0 = wb + 704;         //   upper band's columns lo | hi << 11, owner lane << 22
-    uint32_t* w_q1 = wb + 768;         //   lower band's columns lo | hi << 11
-    uint32_t* w_sx = wb + 832;         //   first tile column | tile row << 10
+    uint32_t* w_key = wb + 128;        // depth bits
+    uint32_t* w_own = wb + 192;        // scratch of wave_owner
+    float4* w_c0 = reinterpret_cast<float4*>(wb + 256);   // span constants of the Gaussian (cull.h: SpanPre): B, 1/A, 2 tau A, det
+    float4* w_c1 = reinterpret_cast<float4*>(wb + 512);   //   ey (negative: no culling), y*, mean x, mean y
+    uint32_t* w_tpre = wb + 768;       // EMIT, per span of the window: inclusive prefix of the spans' widths
+    uint32_t* w_q0 = wb + 832;         //   upper band's columns lo | hi << 11, owner lane << 22
+    uint32_t* w_q1 = wb + 896;         //   lower band's columns lo | hi << 11
+    uint32_t* w_sx = wb + 960;         //   first tile column | tile row << 10
     // The first kernel behind the preprocess pass hands the partial sums of R to the host: plain stores into its pinned buffer
     // (a copy command of 8 KB costs a 5-us blit kernel on the stream); the event behind this kernel tells the host they are there.
     if (!EMIT && host_r != nullptr && blockIdx.x == 0 && tid < R_SLOTS) host_r[tid * R_SLOT_STRIDE] = r_slots[tid * R_SLOT_STRIDE];
@@ -603,28 +696,37 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
             rmax.y = min(rmax.y, by1);
             if (rmax.x > rmin.x && rmax.y > rmin.y) {
                 h = rmax.y - rmin.y;
-                w_xy[lane] = rec.xy;
-                w_co[lane] = rec.co;
+                // the span constants ONCE per Gaussian (two square roots, a logarithm, three reciprocals), not once per row item
+                const SpanPre pre = span_prepare(rec.co, rad);
+                w_c0[lane] = make_float4(pre.B, pre.rcpA, pre.twotauA, pre.det);
+                w_c1[lane] = make_float4(pre.cull ? pre.ey : -1.0f, pre.ystar, rec.xy.x, rec.xy.y);
                 w_rect[lane] = rmin.x | (rmax.x << 10) | (rmin.y << 21);
-                w_rad[lane] = (uint32_t)rad;
                 if (EMIT) w_key[lane] = key;
             }
         }
-        const uint32_t hincl = wave_inclusive_scan(h, lane);
-        uint32_t rows_total = (uint32_t)__shfl((int)hincl, 63, 64);
+        const uint32_t hincl = wave_inclusive_scan_dpp(h);
+        uint32_t rows_total = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63);
         w_pre[lane] = hincl;
         wave_lds_fence();
         if MI_ABLATE(1 << 20) rows_total = 0;
         for (uint32_t w0 = 0; w0 < rows_total; w0 += 64) {  // windows of 64 (Gaussian, tile row) items
             const uint32_t k = w0 + (uint32_t)lane;
             uint32_t width = 0;
+            const uint32_t g = wave_owner(w_own, hincl - h, hincl, w0, lane);
             if (k < rows_total) {
-                const int g = wave_owner(w_pre, k);
-                const uint32_t prev = g == 0 ? 0u : w_pre[g - 1];
+                const uint32_t prev = g == 0u ? 0u : w_pre[g - 1];
                 const uint32_t packed = w_rect[g];
+                const float4 c0 = w_c0[g], c1 = w_c1[g];
                 const uint32_t cx0 = packed & 1023u, cx1 = (packed >> 10) & 2047u, ty = (packed >> 21) + (k - prev);
-                const float2 xy = w_xy[g];
-                const SpanPre pre = span_prepare(w_co[g], (int)w_rad[g]);
+                SpanPre pre;
+                pre.B = c0.x;
+                pre.rcpA = c0.y;
+                pre.twotauA = c0.z;
+                pre.det = c0.w;
+                pre.cull = c1.x >= 0.f;
+                pre.ey = c1.x;
+                pre.ystar = c1.y;
+                const float2 xy = make_float2(c1.z, c1.w);
                 int lo0, hi0, lo1, hi1;
                 band_columns(pre, xy, (float)(ty * TILE_Y), (int)(2u * cx0), (int)(2u * cx1), lo0, hi0);
                 band_columns(pre, xy, (float)(ty * TILE_Y + 8u), (int)(2u * cx0), (int)(2u * cx1), lo1, hi1);
@@ -634,7 +736,7 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
                     const uint32_t sx0 = (uint32_t)lo >> 1, sx1 = ((uint32_t)hi + 1u) >> 1;
                     if (EMIT) {
                         width = sx1 - sx0;
-                        w_q0[lane] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | ((uint32_t)g << 22);
+                        w_q0[lane] = (uint32_t)lo0 | ((uint32_t)hi0 << 11) | (g << 22);
                         w_q1[lane] = (uint32_t)lo1 | ((uint32_t)hi1 << 11);
                         w_sx[lane] = sx0 | (ty << 10);
                     } else {
@@ -655,25 +757,25 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
                 }
             }
             if (EMIT && !MI_ABLATE(1 << 16)) {
-                const uint32_t tincl = wave_inclusive_scan(width, lane);
-                const uint32_t tiles_total = (uint32_t)__shfl((int)tincl, 63, 64);
+                const uint32_t tincl = wave_inclusive_scan_dpp(width);
+                const uint32_t tiles_total = (uint32_t)__builtin_amdgcn_readlane((int)tincl, 63);
                 w_tpre[lane] = tincl;
                 wave_lds_fence();
                 for (uint32_t t0 = 0; t0 < tiles_total; t0 += 64) {   // windows of 64 tiles of the spans
                     const uint32_t kk = t0 + (uint32_t)lane;
+                    const uint32_t o = wave_owner(w_own, tincl - width, tincl, t0, lane);
                     if (kk < tiles_total) {
-                        const int o = wave_owner(w_tpre, kk);
-                        const uint32_t prevt = o == 0 ? 0u : w_tpre[o - 1];
+                        const uint32_t prevt = o == 0u ? 0u : w_tpre[o - 1];
                         const uint32_t q0 = w_q0[o], q1 = w_q1[o], sx = w_sx[o];
                         const uint32_t tx = (sx & 1023u) + (kk - prevt), ty = sx >> 10;
                         const uint32_t lo0 = q0 & 2047u, n0 = ((q0 >> 11) & 2047u) - lo0, lo1 = q1 & 2047u, n1 = ((q1 >> 11) & 2047u) - lo1;
                         const uint32_t c = 2u * tx;
                         const uint32_t qmask = (uint32_t)(c - lo0 < n0) | ((uint32_t)(c + 1u - lo0 < n0) << 1) |
                                                ((uint32_t)(c - lo1 < n1) << 2) | ((uint32_t)(c + 1u - lo1 < n1) << 3);
-                        if (qmask != 0u) {
-                            const uint32_t g = q0 >> 22;
+                        if (qmask != 0u && !MI_ABLATE(1 << 17)) {
+                            const uint32_t gg = q0 >> 22;
                             const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
-                            entries[slot] = make_uint2(w_key[g], (uint32_t)(chunk * 64 + (int)g) | (qmask << ID_BITS));
+                            if (!MI_ABLATE(1 << 19)) entries[slot] = make_uint2(w_key[gg], (uint32_t)(chunk * 64 + (int)gg) | (qmask << ID_BITS));
                         }
                     }
                 }
@@ -690,14 +792,9 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
             for (int x0 = 0; x0 < (int)gx; x0 += 64) {
                 const int x = x0 + lane;
                 int v = x < (int)gx ? s_grid[y * stride + x] : 0;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(v, o, 64);
-                    if (lane >= o) v += t;
-                }
-                v += carry;
+                v = (int)wave_inclusive_scan_dpp((uint32_t)v) + carry;   // (two's complement: the signed differences add up like unsigned words)
                 if (x < (int)gx) my_partial[y * (int)gx + x] = (uint32_t)v;
-                carry = __shfl(v, 63, 64);
+                carry = __builtin_amdgcn_readlane(v, 63);
             }
         }
     }
@@ -907,6 +1004,149 @@ __global__ void __launch_bounds__(256) verify_entries_kernel(uint32_t ntiles, co
     uint32_t n = 0;
     for (uint32_t i = r.x + threadIdx.x; i < r.y; i += 256) n += entries[i].y == 0u;
     if (n) atomicAdd(unwritten, n);
+}
+
+// ---- per-tile sort of short lists: one WAVE per tile, bitonic network in registers ------------------------------------
+// Lists of up to 2048 entries (every list of a 1 M-Gaussian 1080p view; most of a 5 M-Gaussian one) are ordered by ONE wave
+// each, with no LDS and no barrier: lane l holds the EPL consecutive elements l EPL .. l EPL + EPL - 1 of the list padded to
+// N = 64 EPL (EPL = 4 / 8 / 16 / 32 by list length), each as one 64-bit word  depth bits << 32 | id << 4 | quadrant mask  -- ids
+// are distinct inside a tile, so ordering the words orders by (depth bits, id): the contract's order, ties included, with no
+// second pass.
+//   * The words are compared as binary64 numbers: depth bits are those of a positive finite float (sign clear, exponent field
+//     below 0xFF), so the word's top twelve bits are a binary64 exponent below 0x7FF -- never NaN or infinity --, and positive
+//     binary64 numbers order like their bit patterns.  v_min_f64 / v_max_f64 are a 64-bit compare-exchange in TWO instructions;
+//     v_cmp_lt_u64 + four v_cndmask_b32, the integer form, measured 0.087 ms per cfg3 view.
+//   * The network is the all-ascending form of the bitonic sorter: stage K first compares element i with i ^ (K - 1) (the mirror
+//     image inside its block of K), then i with i ^ j for j = K / 4 .. 1; the smaller word always goes to the smaller index, so no
+//     step carries a direction.  Distances below EPL stay inside a lane (register pairs); the others pair lane l with
+//     l ^ M: DPP moves for M = 1, 2, 3, 4, 7, 8, 15 (quad_perm, row_half_mirror, row_mirror, row_shl / row_shr under bank masks),
+//     ds_swizzle for 16 and 31, ds_bpermute for 32 and 63 -- 21 of the 45 steps of a 512-entry list cross lanes.
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
+{
+    auto dpp = [](uint32_t old, uint32_t src, auto ctrl, auto bank) {
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, decltype(ctrl)::value, 0xF, decltype(bank)::value, false);
+    };
+    using std::integral_constant;
+    if constexpr (M == 1) return dpp(0u, v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{});         // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp(0u, v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{});    // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return dpp(0u, v, integral_constant<int, 0x1B>{}, integral_constant<int, 0xF>{});    // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return dpp(0u, v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{});   // row_half_mirror
+    else if constexpr (M == 15) return dpp(0u, v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{});  // row_mirror
+    else if constexpr (M == 4) {   // lanes 0-3 / 8-11 of a row take lane + 4 (row_shl), the others lane - 4 (row_shr)
+        const uint32_t t = dpp(0u, v, integral_constant<int, 0x104>{}, integral_constant<int, 0x5>{});
+        return dpp(t, v, integral_constant<int, 0x114>{}, integral_constant<int, 0xA>{});
+    } else if constexpr (M == 8) {
+        const uint32_t t = dpp(0u, v, integral_constant<int, 0x108>{}, integral_constant<int, 0x3>{});
+        return dpp(t, v, integral_constant<int, 0x118>{}, integral_constant<int, 0xC>{});
+    } else if constexpr (M == 16 || M == 31) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);   // bit mode: lane ^ M inside 32 lanes
+    else return (uint32_t)__shfl_xor((int)v, M, 64);   // 32, 63
+}
+template <int M>
+__device__ __forceinline__ double lane_xor64(double v)
+{
+    const uint64_t w = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = lane_xor<M>((uint32_t)w), hi = lane_xor<M>((uint32_t)(w >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void minmax64(double& lo, double& hi)   // (inline asm: no canonicalisation of the operands in front of it)
+{
+    double mn, mx;
+    asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(mn), "=&v"(mx) : "v"(lo), "v"(hi));
+    lo = mn;
+    hi = mx;
+}
+
+// one step of stage K: FLIP -- partner i ^ (K - 1) -- or distance J
+template <int EPL, int K, int J, bool FLIP>
+__device__ __forceinline__ void bitonic_step(double (&a)[EPL], int lane)
+{
+    if constexpr (FLIP && K > EPL) {
+        // i ^ (K - 1) = (lane ^ (K / EPL - 1)) * EPL + (EPL - 1 - r): the mirrored register of the mirrored lane
+        constexpr int M = K / EPL - 1;
+        const bool lower = (lane & ((M + 1) >> 1)) == 0;
+        double o[EPL];
+#pragma unroll
+        for (int r = 0; r < EPL; r++) o[r] = lane_xor64<M>(a[EPL - 1 - r]);
+#pragma unroll
+        for (int r = 0; r < EPL; r++) {
+            double x = a[r], y = o[r];
+            minmax64(x, y);
+            a[r] = lower ? x : y;
+        }
+    } else if constexpr (!FLIP && J >= EPL) {
+        constexpr int M = J / EPL;
+        const bool lower = (lane & M) == 0;
+#pragma unroll
+        for (int r = 0; r < EPL; r++) {
+            double x = a[r], y = lane_xor64<M>(a[r]);
+            minmax64(x, y);
+            a[r] = lower ? x : y;
+        }
+    } else {
+        constexpr int X = FLIP ? K - 1 : J;   // in-lane partner r ^ X
+#pragma unroll
+        for (int r = 0; r < EPL; r++)
+            if ((r ^ X) > r) minmax64(a[r], a[r ^ X]);
+    }
+}
+template <int EPL, int K, int J>
+__device__ __forceinline__ void bitonic_tail(double (&a)[EPL], int lane)   // distances J, J / 2, .. 1 of stage K, then the next stage
+{
+    if constexpr (J >= 1) {
+        bitonic_step<EPL, K, J, false>(a, lane);
+        bitonic_tail<EPL, K, J / 2>(a, lane);
+    } else if constexpr (K < 64 * EPL) {
+        bitonic_step<EPL, 2 * K, 0, true>(a, lane);
+        bitonic_tail<EPL, 2 * K, K / 2>(a, lane);
+    }
+}
+
+template <int EPL>
+__device__ __forceinline__ void tile_sort_in_wave(const uint2* __restrict__ seg, int n, uint32_t* __restrict__ out, int lane)
+{
+    double a[EPL];
+#pragma unroll
+    for (int r = 0; r < EPL; r++) {
+        const int e = lane * EPL + r;
+        uint64_t w = 0x7FEFFFFFFFFFFFFFull;   // padding: the largest finite binary64, behind every entry
+        if (e < n) {
+            const uint2 p = seg[e];
+            w = ((uint64_t)p.x << 32) | __builtin_rotateleft32(p.y, 4);   // id | mask << 28  ->  id << 4 | mask
+        }
+        a[r] = __builtin_bit_cast(double, w);
+    }
+    bitonic_step<EPL, 2, 0, true>(a, lane);
+    bitonic_tail<EPL, 2, 0>(a, lane);
+#pragma unroll
+    for (int r = 0; r < EPL; r++) {
+        const int e = lane * EPL + r;
+        if (e < n) out[e] = __builtin_rotateright32((uint32_t)__builtin_bit_cast(uint64_t, a[r]), 4);
+    }
+}
+
+constexpr int TILE_SORT_WAVE_MAX = 2048;   // longest list the wave kernels order (EPL = 32); longer ones: tile_sort_kernel below
+// LONG = false: lists of 1 .. 1024 entries (EPL = 4 / 8 / 16: 48 VGPRs); LONG = true: 1025 .. 2048 (EPL = 32), launched only when a
+// tile needs it -- one kernel for both would run the short lists at the long ones' register count.
+template <bool LONG>
+__global__ void __launch_bounds__(256) tile_sort_wave_kernel(uint32_t ntiles, const uint2* __restrict__ ranges,
+                                                              const uint2* __restrict__ entries, uint32_t* __restrict__ blend_list)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const uint2* seg = entries + range.x;
+    uint32_t* out = blend_list + range.x;
+    if constexpr (LONG) {
+        if (n > 1024 && n <= TILE_SORT_WAVE_MAX) tile_sort_in_wave<32>(seg, n, out, lane);
+    } else {
+        if (n == 0 || n > 1024) return;
+        if (n <= 256) tile_sort_in_wave<4>(seg, n, out, lane);
+        else if (n <= 512) tile_sort_in_wave<8>(seg, n, out, lane);
+        else tile_sort_in_wave<16>(seg, n, out, lane);
+    }
 }
 
 template <int LO, int CAP, bool GLOBAL_FALLBACK, int NT>

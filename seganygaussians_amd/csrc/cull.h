@@ -19,6 +19,12 @@
 
 namespace mirast {
 
+// Square root of the cull's closed forms: v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf (a dozen instructions more; six
+// of them per (Gaussian, row) item were a third of the count / emit passes' arithmetic).  Every extent computed here carries 0.1 %
+// + 0.01 px of slack, and the count pass, the emit pass and the full-list masks all call these same functions: one more ulp moves
+// no decision relative to another.
+__device__ __forceinline__ float cull_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 // Lean lists: the part of a Gaussian's reference tile rect [rmin, rmax) that the ellipse { q <= tau_big } can meet at all:
 // its axis-aligned bounding box |dx| <= sqrt(2 tau_big C / det), |dy| <= sqrt(2 tau_big A / det).  tau_big = ln(255 o) plus
 // the margin: 3e-5 of mag_max, the largest magnitude the terms of `power` reach anywhere in the rect (radius + 15 px), + 2e-4.  The 3-sigma SQUARE of the reference is about twice that area on the benchmark scene.
@@ -36,7 +42,7 @@ __device__ __forceinline__ void shrink_rect(float2 xy, float4 co, int rad, uint2
     const float mag_max = (0.5f * (A + C) + fabsf(B)) * m * m;
     const float tau_big = __logf(255.0f * o) + 3e-5f * mag_max + 2e-4f;
     const float s = 2.0f * tau_big * __builtin_amdgcn_rcpf(det);
-    const float ex = sqrtf(s * C) * 1.001f + 0.01f, ey = sqrtf(s * A) * 1.001f + 0.01f;
+    const float ex = cull_sqrt(s * C) * 1.001f + 0.01f, ey = cull_sqrt(s * A) * 1.001f + 0.01f;
     if (!(ex < 1e9f && ey < 1e9f)) return;  // overflow / NaN: keep the rect
     // tile column tx holds pixels 16 tx .. 16 tx + 15: it meets [x - ex, x + ex] iff tx >= (x - ex - 15) / 16 and tx <= (x + ex) / 16
     const float lx = floorf((xy.x - ex - 15.0f) * (1.0f / 16.0f)), hx = floorf((xy.x + ex) * (1.0f / 16.0f)) + 1.0f;
@@ -77,7 +83,7 @@ __device__ __forceinline__ SpanPre span_prepare(float4 co, int rad)
     const float mag_max = (0.5f * (A + C) + fabsf(B)) * m * m;
     const float tau_s = __logf(255.0f * o) + 3e-5f * mag_max + 2e-4f;
     const float s = 2.0f * tau_s * __builtin_amdgcn_rcpf(det);
-    const float ex = sqrtf(s * C), ey = sqrtf(s * A) * 1.001f + 0.01f;
+    const float ex = cull_sqrt(s * C), ey = cull_sqrt(s * A) * 1.001f + 0.01f;
     if (!(ex < 1e9f && ey < 1e9f)) p.cull = false;  // overflow / NaN
     p.B = B;
     p.rcpA = __builtin_amdgcn_rcpf(A);
@@ -104,7 +110,7 @@ __device__ __forceinline__ void band_columns(const SpanPre& p, float2 xy, float 
     }
     const float dyr = fminf(dh, fmaxf(dl, -p.ystar)), dyl = fminf(dh, fmaxf(dl, p.ystar));
     const float Dr = fmaxf(p.twotauA - p.det * dyr * dyr, 0.f), Dl = fmaxf(p.twotauA - p.det * dyl * dyl, 0.f);
-    float dxmax = (sqrtf(Dr) - p.B * dyr) * p.rcpA, dxmin = (-sqrtf(Dl) - p.B * dyl) * p.rcpA;
+    float dxmax = (cull_sqrt(Dr) - p.B * dyr) * p.rcpA, dxmin = (-cull_sqrt(Dl) - p.B * dyl) * p.rcpA;
     dxmax += 1e-3f * fabsf(dxmax) + 0.01f;
     dxmin -= 1e-3f * fabsf(dxmin) + 0.01f;
     // pixel x = mean.x - dx in [x - dxmax, x - dxmin]; column c holds pixels 8c .. 8c + 7

@@ -20,11 +20,8 @@
 #include "knn_smooth.h"
 #include "knn.h"
 #include "blend_bwd.h"
-#ifdef MI_RAST_PROFILING
-#include "../../tools/experiments/blend_bwd_wave_lab.h"   // the same kernel with ablation masks, phase timers and rejected variants
-#else
-#include "blend_bwd_wave.h"
-#endif
+#include "blend_bwd_wave.h"   // (the profiling build compiles the PRODUCT kernel too: what tools/ measure is what ships; the ablation
+                              // masks and rejected variants of rounds 2-5 are a record under tools/experiments/, compiled nowhere)
 #include "blend_fwd.h"
 #include "blend_fwd_wave.h"
 #ifdef MI_RAST_PROFILING
@@ -81,6 +78,8 @@ constexpr int MAX_DEVICES = 64;
 struct HostSync {
     int* pinned = nullptr;   // R partial sums, then {R, longest tile list} of the range scan
     int* pinned_dev = nullptr;  // the same buffer as the kernels address it (they store into it directly)
+    uint64_t* fp = nullptr;     // partial fingerprints (mi_rast_fingerprint), [MI_FP_MAX][FP_BLOCKS]
+    uint64_t* fp_dev = nullptr;
     hipEvent_t ev = nullptr;
     hipEvent_t ev2 = nullptr;
     bool ok = false;
@@ -89,6 +88,8 @@ struct HostSync {
         if (ok) return true;
         if (hipHostMalloc((void**)&pinned, (R_SLOTS * R_SLOT_STRIDE + 16) * sizeof(int), hipHostMallocMapped) != hipSuccess) return false;
         if (hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&fp, (size_t)MI_FP_MAX * FP_BLOCKS * sizeof(uint64_t), hipHostMallocMapped) != hipSuccess) return false;
+        if (hipHostGetDevicePointer((void**)&fp_dev, fp, 0) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess) return false;
         ok = true;
@@ -100,9 +101,11 @@ struct HostSync {
         if (ev) (void)hipEventDestroy(ev);
         if (ev2) (void)hipEventDestroy(ev2);
         if (pinned) (void)hipHostFree(pinned);
+        if (fp) (void)hipHostFree(fp);
     }
 };
 thread_local HostSync g_host_sync_tl[MAX_DEVICES];
+thread_local int g_last_longest_run[MAX_DEVICES];   // of this thread's last forward per device (mi_rast_last_longest_run)
 
 int current_device()
 {
@@ -452,6 +455,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     const bool verify = !full && (flags & MI_RAST_VERIFY_LISTS) != 0;
     if (R > 0) {
         if (verify) HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint2), stream));
+#ifdef MI_RAST_PROFILING
+        // timing experiments that leave list slots unwritten (tools/abl_emit.sh): zeros instead of stale ids, so that the blends stay in bounds
+        if (g_ablate_fwd & ((1 << 16) | (1 << 17) | (1 << 19) | (1 << 20))) HIP_TRY(hipMemsetAsync(bin.entries, 0, (size_t)R * sizeof(uint2), stream));
+#endif
         {
             StageTimer t(stream, MI_STAGE_EMIT);
             const size_t emit_lds = bin_lds + 8 * 1024 * sizeof(uint32_t);
@@ -484,20 +491,26 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         const int* key_bits = img.num_rendered + R_SLOTS * R_SLOT_STRIDE + NR_KEY_BITS;
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
-            // three list-length classes (256 threads + 36 KB of LDS, 1024 threads + 112 KB, 1024 threads + 144 KB); a class is launched only if
-            // some tile needs it.  The longest list was copied to the host right after the range scan, which
-            // finished before the emit pass above even started: this wait does not stall the queue.
+            // lists of up to 2048 entries: one wave per tile (bitonic network in registers); longer ones: two classes of the LDS radix
+            // sort (1024 threads + 112 KB, 1024 threads + 144 KB / HBM ping-pong), launched only if some tile needs them.  The longest
+            // list was copied to the host right after the range scan, which finished before the emit pass above even started: this
+            // wait does not stall the queue.
 #define LAUNCH_TILE_SORT(LO, CAP, FB, NT)                                                                                 \
     hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges,  \
                        bin.entries, bin.scratch, key_bits, bin.blend_list)
-            LAUNCH_TILE_SORT(0, 2048, false, 256);
+            hipLaunchKernelGGL(tile_sort_wave_kernel<false>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges,
+                               (const uint2*)bin.entries, bin.blend_list);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
             img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + NR_RUN_BOUNDS, (uint32_t)ntiles);
+            g_last_longest_run[dev] = (int)img.longest_run;
             // lean lists: the counts are the lists' exact lengths (bin_spans_kernel), their sum a lower bound of R
             if (full ? g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + NR_TOTAL] != R : g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + NR_TOTAL] > R)
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + NR_LONGEST];
-            if (max_tile_count > 2048) LAUNCH_TILE_SORT(2048, 6144, false, 1024);
+            if (max_tile_count > 1024)
+                hipLaunchKernelGGL(tile_sort_wave_kernel<true>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges,
+                                   (const uint2*)bin.entries, bin.blend_list);
+            if (max_tile_count > TILE_SORT_WAVE_MAX) LAUNCH_TILE_SORT(TILE_SORT_WAVE_MAX, 6144, false, 1024);
             if (max_tile_count > 6144) LAUNCH_TILE_SORT(6144, 8192, true, 1024);
 #undef LAUNCH_TILE_SORT
         }
@@ -507,6 +520,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         // land (the next forward of this thread, on another stream, would read them)
         HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
         img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + NR_RUN_BOUNDS, (uint32_t)ntiles);
+        g_last_longest_run[dev] = (int)img.longest_run;
     }
     return MI_RAST_OK;
 }
@@ -899,9 +913,11 @@ size_t mi_rast_binning_layout(int R, size_t* off)
 {
     const size_t r = R > 0 ? (size_t)R : 1;
     Carver c;
+    // the blend list first: it is all the blend kernels (and a caller that keeps a view's lists, mi_rast_forward_reuse) need of this
+    // buffer, at an offset that does not depend on R
+    off[MI_BIN_BLEND_LIST] = c.take(r * sizeof(uint32_t));
     off[MI_BIN_ENTRIES] = c.take(r * sizeof(uint2));
     off[MI_BIN_SCRATCH] = c.take(r * sizeof(uint2));
-    off[MI_BIN_BLEND_LIST] = c.take(r * sizeof(uint32_t));
     return c.off;
 }
 
@@ -929,37 +945,14 @@ int mi_rast_profile_read(float* ms)
     return MI_RAST_OK;
 }
 
-int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_rast_resize_fn binning_buffer,
-                    void* binning_user, mi_rast_resize_fn image_buffer, void* image_user, int P, int D, int M,
-                    int channels, const float* background, int width, int height, const float* means3D,
-                    const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
-                    float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-                    const float* mask, float* out_color, float* out_mask, float* out_depth, int* radii, int debug,
-                    int flags, void* features_ready_event, float* dL_dcolor_next, void* stream_, int* num_rendered)
+// The blend stage of a forward: CF/cuda_rasterizer/rasterizer_impl.cu:319-335 (+ the zero fills for this view's backward).  Shared by
+// mi_rast_forward and mi_rast_forward_reuse.
+static int blend_forward_stage(const ViewParams& vp, hipStream_t stream, GeomPtrs& geom, ImgPtrs& img, BinPtrs& bin, int P, int channels,
+                               int width, int height, const float* background, const float* colors_precomp, const float* mask,
+                               float* out_color, float* out_mask, float* out_depth, int debug, int flags, void* features_ready_event,
+                               float* dL_dcolor_next)
 {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (num_rendered) *num_rendered = 0;
-    if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
-    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 1 .. 256)");
-    if (mask && channels != 3) return fail(MI_RAST_ERR_INVALID, "mask/depth variant is built for 3 channels");
-    // CF/cuda_rasterizer/rasterizer_impl.cu:242-245
-    if (channels != 3 && colors_precomp == nullptr)
-        return fail(MI_RAST_ERR_NON_RGB, "For non-RGB, provide precomputed Gaussian colors!");
-    if (!num_rendered || !radii || !out_color) return fail(MI_RAST_ERR_INVALID, "null output pointer");
-
-    const ViewParams vp = make_view(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, scale_modifier, width, height);
     int rc;
-
-    GeomPtrs geom;
-    ImgPtrs img;
-    BinPtrs bin;
-    rc = geometry_and_binning(geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P,
-                              D, M, width, height, means3D, shs, colors_precomp != nullptr, opacities, scales,
-                              rotations, cov3D_precomp, vp, prefiltered, radii, debug, flags, stream, geom, img, bin,
-                              num_rendered);
-    if (rc) return rc;
-
     const float* feature_ptr = colors_precomp != nullptr ? colors_precomp : geom.rgb;  // rasterizer_impl.cu:321
     if (features_ready_event != nullptr) {
         // everything above depends on the geometry only; colors_precomp may still be in the making (mi_rast.h)
@@ -1070,6 +1063,116 @@ int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_r
     return MI_RAST_OK;
 }
 
+int mi_rast_forward(mi_rast_resize_fn geometry_buffer, void* geometry_user, mi_rast_resize_fn binning_buffer,
+                    void* binning_user, mi_rast_resize_fn image_buffer, void* image_user, int P, int D, int M,
+                    int channels, const float* background, int width, int height, const float* means3D,
+                    const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                    float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                    const float* mask, float* out_color, float* out_mask, float* out_depth, int* radii, int debug,
+                    int flags, void* features_ready_event, float* dL_dcolor_next, void* stream_, int* num_rendered)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (num_rendered) *num_rendered = 0;
+    if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
+    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 1 .. 256)");
+    if (mask && channels != 3) return fail(MI_RAST_ERR_INVALID, "mask/depth variant is built for 3 channels");
+    // CF/cuda_rasterizer/rasterizer_impl.cu:242-245
+    if (channels != 3 && colors_precomp == nullptr)
+        return fail(MI_RAST_ERR_NON_RGB, "For non-RGB, provide precomputed Gaussian colors!");
+    if (!num_rendered || !radii || !out_color) return fail(MI_RAST_ERR_INVALID, "null output pointer");
+
+    const ViewParams vp = make_view(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, scale_modifier, width, height);
+    int rc;
+
+    GeomPtrs geom;
+    ImgPtrs img;
+    BinPtrs bin;
+    rc = geometry_and_binning(geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P,
+                              D, M, width, height, means3D, shs, colors_precomp != nullptr, opacities, scales,
+                              rotations, cov3D_precomp, vp, prefiltered, radii, debug, flags, stream, geom, img, bin,
+                              num_rendered);
+    if (rc) return rc;
+
+    return blend_forward_stage(vp, stream, geom, img, bin, P, channels, width, height, background, colors_precomp, mask, out_color, out_mask,
+                               out_depth, debug, flags, features_ready_event, dL_dcolor_next);
+}
+
+// Extension (no counterpart in the reference; include/mi_rast.h): the blend stage alone over the state a previous mi_rast_forward
+// of the SAME geometry, camera and list mode left in its buffers.
+int mi_rast_forward_reuse(int P, int channels, int R, const float* background, int width, int height, const float* colors_precomp,
+                          char* geom_buffer, char* binning_buffer, const void* cached_ranges, const int* cached_words, char* img_buffer,
+                          int longest_run, const float* mask, float* out_color, float* out_mask, float* out_depth, int flags,
+                          void* features_ready_event, float* dL_dcolor_next, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0 || width <= 0 || height <= 0) return fail(MI_RAST_ERR_INVALID, "P, width and height must be positive");
+    if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 1 .. 256)");
+    if (mask && channels != 3) return fail(MI_RAST_ERR_INVALID, "mask/depth variant is built for 3 channels");
+    if (channels != 3 && colors_precomp == nullptr)
+        return fail(MI_RAST_ERR_NON_RGB, "For non-RGB, provide precomputed Gaussian colors!");
+    if (!geom_buffer || !binning_buffer || !cached_ranges || !cached_words || !img_buffer || !out_color) return fail(MI_RAST_ERR_INVALID, "null pointer");
+    ViewParams vp;
+    std::memset(&vp, 0, sizeof(vp));
+    vp.W = width;
+    vp.H = height;
+    vp.grid_x = (width + TILE_X - 1) / TILE_X;
+    vp.grid_y = (height + TILE_Y - 1) / TILE_Y;
+    const int debug = 0;
+    GeomPtrs geom = geom_from(geom_buffer, P);
+    BinPtrs bin = bin_from(binning_buffer, R);
+    ImgPtrs img = img_from(img_buffer, width, height);
+    const uint32_t ntiles = vp.grid_x * vp.grid_y;
+    img.longest_run = longest_run > 0 ? std::min((uint32_t)longest_run, xcd_max_run(ntiles)) : 0u;
+    {
+        // the per-view words of the image buffer that the binning stages of the cached forward wrote: tile ranges, {R, longest list,
+        // key bits}, the XCD run boundaries -- copied; the per-tile walk counters of the blend kernels -- zeroed (binning.h)
+        StageTimer t(stream, MI_STAGE_TILE_SCAN);
+        hipLaunchKernelGGL(reuse_image_state_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, ntiles, (const uint2*)cached_ranges,
+                           cached_words, img.ranges, img.num_rendered + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv);
+    }
+    STAGE_CHECK("reuse image state");
+    return blend_forward_stage(vp, stream, geom, img, bin, P, channels, width, height, background, colors_precomp, mask, out_color, out_mask,
+                               out_depth, debug, flags, features_ready_event, dL_dcolor_next);
+}
+
+// Content fingerprints of up to MI_FP_MAX device arrays (a 64-bit sum of position-dependent word hashes each): what a caller keys
+// reuse decisions on when tensors are recomputed per call (activation outputs) and identity says nothing.  Synchronous: one kernel,
+// then the calling thread waits for `stream`.
+int mi_rast_fingerprint(int n, const void* const* ptrs, const size_t* nbytes, uint64_t* out, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n > MI_FP_MAX) return fail(MI_RAST_ERR_INVALID, "mi_rast_fingerprint: at most 8 arrays");
+    if (n == 0) return MI_RAST_OK;
+    const int dev = current_device();
+    if (dev < 0) return fail(MI_RAST_ERR_HIP, "hipGetDevice failed (or device ordinal >= 64)");
+    HostSync& hs = g_host_sync_tl[dev];
+    if (!hs.init()) return fail(MI_RAST_ERR_HIP, "cannot allocate pinned host buffer / event");
+    FingerprintArgs a;
+    for (int k = 0; k < MI_FP_MAX; k++) {
+        a.ptr[k] = k < n ? (const uint32_t*)ptrs[k] : nullptr;
+        a.words[k] = k < n ? (unsigned long long)(nbytes[k] / 4) : 0ull;
+        if (k < n && ((nbytes[k] & 3) || (reinterpret_cast<uintptr_t>(ptrs[k]) & 3))) return fail(MI_RAST_ERR_INVALID, "mi_rast_fingerprint: arrays of 4-byte words");
+    }
+    hipLaunchKernelGGL(fingerprint_kernel, dim3(FP_BLOCKS, n), dim3(256), 0, stream, a, (unsigned long long*)hs.fp_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < n; k++) {
+        uint64_t sum = 0;
+        for (int b = 0; b < FP_BLOCKS; b++) sum += hs.fp[k * FP_BLOCKS + b];
+        out[k] = sum;
+    }
+    return MI_RAST_OK;
+}
+
+// The longest XCD run of tiles of the calling thread's last mi_rast_forward on the current device (what sizes the forward blend's
+// grid): a caller that keeps the buffers of that forward for mi_rast_forward_reuse passes it back; 0 if unknown.
+int mi_rast_last_longest_run(void)
+{
+    const int dev = current_device();
+    return dev < 0 ? 0 : g_last_longest_run[dev];
+}
+
 int mi_rast_backward(int P, int D, int M, int channels, int R, const float* background, int width, int height,
                      const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                      float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -1106,18 +1209,6 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         int cstride = channels;
         int cr_blk = 0;   // channels of a partial block that exist (blend_bwd_wave.h: CR == 0)
         const uint32_t nt_ = vp.grid_x * vp.grid_y;
-#ifdef MI_RAST_PROFILING
-#define LAUNCH_BWD_WAVE_(WPB, XE, ST, ...)                                                                                    \
-    hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, WPB, XE, ST>), dim3(WPB == 1 ? 32u * xcd_static_len_max(nt_) + 4u * xcd_queued_tiles_max(nt_) : nt_), dim3(64 * WPB), 0,    \
-                       stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
-                       img.final_T, img.n_contrib, dpix_blk, dL_dout_mask, geom.bwd_pack, dcolor_blk, queue_ctr, cstride, cr_blk, g_ablate, img.run_bounds)
-#define LAUNCH_BWD_WAVE_ST(ST, ...)                                                 \
-    do {                                                                            \
-        if (xexp) LAUNCH_BWD_WAVE_(1, true, ST, __VA_ARGS__);                       \
-        else if (g_ablate & 4096) LAUNCH_BWD_WAVE_(4, false, ST, __VA_ARGS__);      \
-        else LAUNCH_BWD_WAVE_(1, false, ST, __VA_ARGS__);                           \
-    } while (0)
-#else
 #define LAUNCH_BWD_WAVE_(XE, ST, ...)                                                                                         \
     hipLaunchKernelGGL((blend_bwd_wave_kernel<__VA_ARGS__, XE, ST>), dim3(32u * xcd_static_len_max(nt_) + 4u * xcd_queued_tiles_max(nt_)), dim3(64), 0,    \
                        stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk, colors_blk, \
@@ -1127,7 +1218,6 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         if (xexp) LAUNCH_BWD_WAVE_(true, ST, __VA_ARGS__);                          \
         else LAUNCH_BWD_WAVE_(false, ST, __VA_ARGS__);                              \
     } while (0)
-#endif
 // (the row stride is a compile-time constant unless the launch handles one channel block of a wider feature)
 #define LAUNCH_BWD_WAVE(C_, CR_, MG_)                                               \
     do {                                                                            \
@@ -1167,29 +1257,6 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
 #undef LAUNCH_BWD_WAVE_ST
 #undef LAUNCH_BWD_WAVE_
     }
-#ifdef MI_RAST_PROFILING
-    if ((g_ablate & 32) && !(g_ablate & 1024)) {
-        float dbg[8 * 13];
-        (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);
-        const char* nm[9] = {"header", "dL staging", "first fill+request", "stage(wait+write)", "scan+request", "S mfma+transpose",
-                             "recurrences", "dF/M mfma", "outputs"};
-        double tot = 0;
-        for (int i = 0; i < 9; i++) tot += dbg[8 * (i + 1) + 7];
-        fprintf(stderr, "[mi_rast debug] bwd wave kernel: %.0f waves, %.0f chunks, %.0f scan blocks; wave-cycles %.4g:", dbg[8 * 12 + 7], dbg[8 * 10 + 7],
-                dbg[8 * 11 + 7], tot);
-        for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * dbg[8 * (i + 1) + 7] / tot);
-        fprintf(stderr, "\n");
-    } else if (g_ablate & 32) {
-        float dbg[88];
-        (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(dbg, geom.bwd_pack, sizeof(dbg), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[mi_rast debug] bwd wave-cycles: head=%.3g dLstage=%.3g recstage=%.3g featstage+select=%.3g chunks+barrierwait=%.3g\n",
-                dbg[14], dbg[22], dbg[30], dbg[38], dbg[46]);
-        fprintf(stderr, "[mi_rast debug] bwd chunks: %.4g of 16 rows, %.4g of them without any contributing pixel; rows: %.4g padding, %.4g with a contributing pixel\n",
-                dbg[54], dbg[62], dbg[70], dbg[78]);
-    }
-#endif
     STAGE_CHECK("render backward");
 
     const float* cov3D_ptr = (cov3D_precomp != nullptr) ? cov3D_precomp : geom.cov3D;  // rasterizer_impl.cu:411

@@ -96,7 +96,7 @@ def shard_range(numel: int, rank: int, world: int):
     return min(numel, rank * per), min(numel, (rank + 1) * per)
 
 
-def sharded_update_async(param: torch.Tensor, grad: torch.Tensor, update_shard, group=None):
+def sharded_update_async(param: torch.Tensor, grad: torch.Tensor, update_shard, group=None, average: bool = False):
     """The exchange of a view-sharded step as reduce-scatter -> rank-local update -> all-gather instead of an all-reduce followed
     by the same update on every rank:
 
@@ -113,7 +113,16 @@ def sharded_update_async(param: torch.Tensor, grad: torch.Tensor, update_shard, 
     (grad already summed over the ranks) and updates the parameter view IN PLACE.  On return `param` holds the updated values of
     every rank's shard once the returned event has fired (CUDA; the call completes everything on CPU tensors and returns
     (None, None)).  Hand the event to rasterizer.set_features_ready_event like allreduce_grads_async's.  Without an initialised
-    process group the update runs over the whole tensor."""
+    process group the update runs over the whole tensor.  `average`: the summed gradient is divided by the world size first
+    (allreduce_grads / ViewShardedStep have the same switch).
+
+    STREAMS -- the caller's part of the contract.  Until the returned event has fired, a side stream reads `grad` and WRITES `param`
+    in place (record_stream only keeps the allocator from reusing their memory):
+      * do not touch `grad` in place before then -- drop it (`param.grad = None`, what optimizer.zero_grad() does by default), never
+        `zero_grad(set_to_none=False)` or an in-place op on it;
+      * every other reader of `param` on the compute stream -- a feature regulariser, evaluation, save_ply -- must first make that
+        stream wait: `torch.cuda.current_stream().wait_event(ev)`.  The next rasterizer forward does this itself when the event was
+        handed to rasterizer.set_features_ready_event (it waits right before its blend stage)."""
     if not (param.is_contiguous() and grad.is_contiguous()) or param.shape != grad.shape:
         raise ValueError("sharded_update_async needs contiguous param / grad of one shape")
     n = param.numel()
@@ -122,9 +131,12 @@ def sharded_update_async(param: torch.Tensor, grad: torch.Tensor, update_shard, 
         update_shard(pf, gf, 0, n)
         return None, None
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if "nccl" in str(dist.get_backend(group)) and not param.is_cuda:
+        raise ValueError("sharded_update_async: an RCCL-only group cannot exchange host tensors")
     per = -(-n // world)
     lo, hi = shard_range(n, rank, world)
-    native = dist.get_backend(group) == "nccl" or not param.is_cuda   # RCCL, or gloo on host tensors
+    # RCCL (also in a mixed "cuda:nccl,cpu:gloo" group), or gloo on host tensors
+    native = (param.is_cuda and "nccl" in str(dist.get_backend(group))) or not param.is_cuda
 
     def run():
         if per * world == n:
@@ -138,6 +150,8 @@ def sharded_update_async(param: torch.Tensor, grad: torch.Tensor, update_shard, 
         if native:
             gshard = torch.empty(per, dtype=gf.dtype, device=gf.device)
             dist.reduce_scatter_tensor(gshard, gin, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                gshard.div_(world)
             update_shard(pshard[:hi - lo], gshard[:hi - lo], lo, hi)
             dist.all_gather_into_tensor(pall, pshard, group=group)   # in place: this rank's shard is where it belongs already
         else:
@@ -146,6 +160,8 @@ def sharded_update_async(param: torch.Tensor, grad: torch.Tensor, update_shard, 
             gsum = gin.clone()
             dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group)
             gshard = gsum[rank * per:(rank + 1) * per]
+            if average:
+                gshard.div_(world)
             update_shard(pshard[:hi - lo], gshard[:hi - lo], lo, hi)
             parts = [torch.empty_like(pshard) for _ in range(world)]
             dist.all_gather(parts, pshard.clone(), group=group)
@@ -175,8 +191,12 @@ def sharded_update_async(param: torch.Tensor, grad: torch.Tensor, update_shard, 
 class ShardedAdam:
     """Adam over this rank's shard of ONE parameter tensor, for `sharded_update_async`: the update torch.optim.Adam(lr, betas, eps)
     applies to the whole tensor (no weight decay, no amsgrad: what SAGA's feature training uses, scene/gaussian_model_ff.py:154-162),
-    with both moment buffers allocated for 1 / world of the rows only -- at 1 M x 32 features and N = 8, 32 MB of optimizer state per
-    rank instead of 256 MB, and an eighth of the optimizer's memory traffic per step.
+    with both moment buffers allocated for this rank's 1 / world of the ELEMENTS only (shard_range cuts the flat tensor, not rows: the
+    bounds move with the world size) -- at 1 M x 32 features and N = 8, 32 MB of optimizer state per rank instead of 256 MB, and an
+    eighth of the optimizer's memory traffic per step.  state_dict() / load_state_dict() gather / scatter the moments to and from the
+    full tensor's layout -- the entries torch.optim.Adam keeps for that parameter ("step", "exp_avg", "exp_avg_sq") -- so that the
+    reference's checkpoints (FeatureGaussianModel.capture / restore, scene/gaussian_model_ff.py:403-437) carry the moments and a run
+    may resume under another world size.
 
         opt = ShardedAdam(lr=0.0025)
         ev, keep = sharded_update_async(features, features.grad, opt)     # features: the replicated parameter
@@ -202,6 +222,48 @@ class ShardedAdam:
         bias1, bias2 = 1.0 - b1 ** self.step, 1.0 - b2 ** self.step
         denom = (self.exp_avg_sq.sqrt() / (bias2 ** 0.5)).add_(self.eps)
         prow.addcdiv_(self.exp_avg, denom, value=-self.lr / bias1)
+
+    def state_dict(self, numel: int, shape=None, group=None) -> dict:
+        """The state torch.optim.Adam holds for the parameter (`numel` elements, viewed as `shape`): {"step", "exp_avg", "exp_avg_sq"}
+        with FULL moment tensors, gathered from the ranks' shards -- a collective when a process group is up: call it on every rank."""
+        full = []
+        for buf in (self.exp_avg, self.exp_avg_sq):
+            if not (dist.is_available() and dist.is_initialized()):
+                full.append(torch.zeros(numel) if buf is None else buf.detach().clone())
+                continue
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            per = -(-numel // world)
+            lo, hi = shard_range(numel, rank, world)
+            if buf is None:
+                raise ValueError("ShardedAdam.state_dict: no step taken yet on this rank")
+            if self.bounds != (lo, hi):
+                raise ValueError(f"ShardedAdam holds elements {self.bounds}; a tensor of {numel} elements gives this rank {(lo, hi)}")
+            mine = torch.zeros(per, dtype=buf.dtype, device=buf.device)
+            mine[:hi - lo].copy_(buf)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            full.append(torch.cat(parts)[:numel])
+        out = {"step": torch.tensor(float(self.step)), "exp_avg": full[0], "exp_avg_sq": full[1]}
+        if shape is not None:
+            out["exp_avg"], out["exp_avg_sq"] = out["exp_avg"].view(shape), out["exp_avg_sq"].view(shape)
+        return out
+
+    def load_state_dict(self, state: dict, group=None) -> None:
+        """Takes {"step", "exp_avg", "exp_avg_sq"} with FULL moment tensors (this class's state_dict, or torch.optim.Adam's state of
+        the parameter) and keeps this rank's elements of them; any world size."""
+        ea, es = state["exp_avg"], state["exp_avg_sq"]
+        if ea.shape != es.shape:
+            raise ValueError("ShardedAdam.load_state_dict: exp_avg and exp_avg_sq differ in shape")
+        numel = ea.numel()
+        world, rank = (dist.get_world_size(group), dist.get_rank(group)) if dist.is_available() and dist.is_initialized() else (1, 0)
+        lo, hi = shard_range(numel, rank, world)
+        if self.bounds is not None and self.bounds != (lo, hi):
+            raise ValueError(f"ShardedAdam holds elements {self.bounds}; the loaded state ({numel} elements, world {world}) gives this rank {(lo, hi)}")
+        dev = self.exp_avg.device if self.exp_avg is not None else ea.device
+        self.exp_avg = ea.detach().reshape(-1)[lo:hi].to(dev).clone()
+        self.exp_avg_sq = es.detach().reshape(-1)[lo:hi].to(dev).clone()
+        self.bounds = (lo, hi)
+        self.step = int(float(state["step"]))
 
 
 class ViewShardedStep:

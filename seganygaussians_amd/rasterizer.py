@@ -134,6 +134,144 @@ def forward_flags(full_lists=None, f32_blend=None, no_cull=None, fast_exp=None, 
         _opts.flags = prev
 
 
+# --------------------------------------------------------------------------------------------------
+# frozen-geometry reuse (opt-in; an extension: the reference recomputes everything per call)
+# --------------------------------------------------------------------------------------------------
+class GeometryCache:
+    """Per-camera cache of what the geometry-only stages of a forward produce (preprocess, binning, per-tile sort): the geometry
+    buffer, the blend lists, the tile ranges + XCD run boundaries, radii and num_rendered.  A later forward of the SAME geometry
+    from the SAME camera runs the blend stage alone (include/mi_rast.h: mi_rast_forward_reuse).  Meant for SAGA's contrastive
+    feature training, which optimises the feature rows only (scene/gaussian_model_ff.py:154-162) and revisits each of ~200 cameras
+    ~50 times (train_contrastive_feature.py:231).
+
+    The key is CONTENT: 64-bit fingerprints (mi_rast_fingerprint) of means3D, opacities, scales, rotations, cov3D_precomp, shs (when
+    they colour the Gaussians), view / projection matrix and camera position, next to the scalar settings.  The reference's
+    renderer passes activation OUTPUTS (gaussian_renderer/__init__.py:337-348: pc.get_opacity, get_scaling, get_rotation), new
+    tensors per call, so storage identity alone would never hit -- and a freed tensor's address can be handed to another one.  A
+    fingerprint is memoised per tensor OBJECT (weak reference) and version counter: a parameter or camera tensor that is passed
+    again unchanged costs nothing, any in-place change (`means3D.add_(...)`, an optimizer step on a geometry tensor) bumps
+    `_version`, gets a new fingerprint and misses.  Tensors seen for the first time are fingerprinted by one kernel, behind which
+    the calling thread waits for the stream.
+
+    Bytes kept per view: the geometry buffer (139 bytes per Gaussian), 4 bytes per blend-list entry, 8 bytes per tile, radii (4 bytes
+    per Gaussian).  Least recently used views are dropped beyond `max_bytes`.
+
+    The cached buffers are SHARED between the forwards of a view: two backward passes of the same cached view must not run at the
+    same time on different streams (they would share the packed-gradient scratch of the geometry buffer); one after the other --
+    what a training loop does -- is fine.  `debug=True` forwards and the full-list / verify modes of the tests are never cached."""
+
+    def __init__(self, max_bytes=64 << 30):
+        import collections
+        self.max_bytes = int(max_bytes)
+        self.enabled = True
+        self.entries = collections.OrderedDict()
+        self.bytes = 0
+        self.hits = self.misses = 0
+        self._memo = {}          # id(tensor) -> (weakref, _version, fingerprint)
+        self.lock = threading.Lock()
+
+    def stats(self):
+        n = self.hits + self.misses
+        return {"hits": self.hits, "misses": self.misses, "hit_rate": (self.hits / n) if n else 0.0, "views": len(self.entries),
+                "bytes_cached": self.bytes}
+
+    def clear(self):
+        with self.lock:
+            self.entries.clear()
+            self._memo.clear()
+            self.bytes = 0
+            self.hits = self.misses = 0
+
+    def fingerprints(self, tensors, dev):
+        """One 64-bit content fingerprint per tensor (None for an absent one); memoised per (tensor object, version)."""
+        import weakref
+        out = [None] * len(tensors)
+        todo = []
+        for k, t in enumerate(tensors):
+            if t is None or t.numel() == 0:
+                continue
+            m = self._memo.get(id(t))
+            if m is not None and m[0]() is t and m[1] == t._version:
+                out[k] = m[2]
+            else:
+                todo.append(k)
+        for g0 in range(0, len(todo), 8):
+            grp = todo[g0:g0 + 8]
+            n = len(grp)
+            ptrs = (C.c_void_p * n)(*[tensors[k].data_ptr() for k in grp])
+            sizes = (C.c_size_t * n)(*[tensors[k].numel() * tensors[k].element_size() for k in grp])
+            res = (C.c_uint64 * n)()
+            with torch.cuda.device(dev):
+                _check(_lib.load().mi_rast_fingerprint(n, ptrs, sizes, res, _stream_ptr(dev)))
+            for k, v in zip(grp, res):
+                t = tensors[k]
+                out[k] = (int(v), tuple(t.shape), str(t.dtype))
+                self._memo[id(t)] = (weakref.ref(t), t._version, out[k])
+        if len(self._memo) > 4096:   # forget tensors that are gone
+            self._memo = {i: m for i, m in self._memo.items() if m[0]() is not None}
+        return out
+
+    def lookup(self, key):
+        with self.lock:
+            e = self.entries.get(key)
+            if e is not None:
+                self.entries.move_to_end(key)
+                self.hits += 1
+            else:
+                self.misses += 1
+            return e
+
+    def insert(self, key, entry):
+        with self.lock:
+            old = self.entries.pop(key, None)
+            if old is not None:
+                self.bytes -= old["bytes"]
+            self.entries[key] = entry
+            self.bytes += entry["bytes"]
+            while self.bytes > self.max_bytes and len(self.entries) > 1:
+                _, dropped = self.entries.popitem(last=False)
+                self.bytes -= dropped["bytes"]
+
+
+_geometry_cache = None
+
+
+def enable_geometry_cache(max_bytes=64 << 30):
+    """Switches the frozen-geometry reuse on for every forward of this process (GeometryCache); returns the cache (`.stats()`).
+    Also switched on by MI_RAST_GEOMETRY_CACHE=<GiB> (or 1: 64 GiB) in the environment, for unchanged reference scripts."""
+    global _geometry_cache
+    if _geometry_cache is None:
+        _geometry_cache = GeometryCache(max_bytes)
+    else:
+        _geometry_cache.max_bytes = int(max_bytes)
+    _geometry_cache.enabled = True
+    return _geometry_cache
+
+
+def disable_geometry_cache(drop=False):
+    """Forwards recompute everything again; the cached views are kept for a later enable_geometry_cache() unless `drop`."""
+    global _geometry_cache
+    if _geometry_cache is not None:
+        _geometry_cache.enabled = False
+        if drop:
+            _geometry_cache = None
+
+
+def geometry_cache():
+    return _geometry_cache
+
+
+if os.environ.get("MI_RAST_GEOMETRY_CACHE", "") not in ("", "0"):
+    try:
+        _gib = float(os.environ["MI_RAST_GEOMETRY_CACHE"])
+    except ValueError:
+        _gib = 1.0
+    enable_geometry_cache(int((64 if _gib == 1.0 else _gib) * (1 << 30)))
+
+
+_NOCACHE_FLAGS = _lib.MI_RAST_FULL_LISTS | _lib.MI_RAST_NO_CULL | _lib.MI_RAST_VERIFY_LISTS | _lib.MI_RAST_TILE_FWD | _lib.MI_RAST_F32_BLEND
+
+
 def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, colors, opacity, mask, scales,
                                rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                image_height, image_width, sh, degree, campos, prefiltered, debug, prezero=False):
@@ -177,6 +315,35 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
             # the DEPTH package always passes a mask (DEPTH/.../__init__.py:323); without one out_mask / out_depth
             # would be left unwritten
             raise RuntimeError("mask must hold one float32 per Gaussian on the GPU (diff_gaussian_rasterization_depth)")
+        # frozen-geometry reuse (opt-in, GeometryCache): same geometry + camera as an earlier forward -> the blend stage alone
+        cache, ckey = _geometry_cache, None
+        if cache is not None and cache.enabled and not debug and not (int(_opts.flags) & _NOCACHE_FLAGS) and not prefiltered:
+            colours_from_sh = col_c is None or col_c.numel() == 0
+            fps = cache.fingerprints([m3_c, op_c, sc_c, rot_c, cov_c, sh_c if colours_from_sh else None, vm_c, pm_c, cp_c], dev)
+            ckey = (dev.index, P, H, W, float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree), int(M) if colours_from_sh else -1,
+                    int(_opts.flags), tuple(fps))
+            hit = cache.lookup(ckey)
+            if hit is not None:
+                img_t = torch.empty(hit["img_bytes"], dtype=torch.uint8, device=dev)
+                with torch.cuda.device(dev):
+                    rc = L.mi_rast_forward_reuse(
+                        P, int(channels), int(hit["num_rendered"]), _dev_ptr(bg_c, "bg", dev), W, H, _dev_ptr(col_c, "colors_precomp", dev),
+                        hit["geom"].data_ptr(), hit["blend_list"].data_ptr(), hit["ranges"].data_ptr(), hit["words"].data_ptr(),
+                        img_t.data_ptr(), int(hit["longest_run"]), _dev_ptr(mk_c, "mask", dev) if with_mask_depth else None,
+                        out_color.data_ptr(), out_mask.data_ptr() if with_mask_depth else None,
+                        out_depth.data_ptr() if with_mask_depth else None, int(_opts.flags),
+                        None if ready is None else C.c_void_p(ready.cuda_event),
+                        None if grad_colors is None else grad_colors.data_ptr(), _stream_ptr(dev))
+                del ready
+                _check(rc)
+                geom_t = hit["geom"].view(-1)        # a new tensor object over the shared storage: the notes below are per forward
+                geom_t.mi_flags = int(_opts.flags)
+                if grad_colors is not None:
+                    geom_t.mi_prezero = grad_colors
+                    geom_t.mi_pack_zeroed = False    # (the packed-gradient scratch is shared between the forwards of a cached view: its backward fills it)
+                res = (hit["num_rendered"], out_color) + ((out_mask, out_depth) if with_mask_depth else ()) + \
+                      (hit["radii"], geom_t, hit["blend_list"], img_t)
+                return res
         with torch.cuda.device(dev):
             rc = L.mi_rast_forward(
                 geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), int(channels),
@@ -199,6 +366,19 @@ def rasterize_gaussians_native(channels, with_mask_depth, background, means3D, c
             if grad_colors is not None:
                 geom.tensor.mi_prezero = grad_colors
         rendered = n.value
+        if ckey is not None:
+            # first visit of this (geometry, camera): keep what the geometry-only stages produced.  The blend list (first field of
+            # the binning buffer, include/mi_rast.h) is copied at its real length, tile ranges and the 16 words behind the R partial
+            # sums likewise; the geometry buffer is kept as it is (this forward's backward shares it).
+            _, ioff = _lib.image_layout(W, H)
+            tiles = ((W + 15) // 16) * ((H + 15) // 16)
+            words = img.tensor[ioff["num_rendered"] + 8192:ioff["num_rendered"] + 8192 + 64].clone()
+            n_list = int(words.view(torch.int32)[0].item()) if rendered > 0 else 0   # entries the lists hold (lean: <= num_rendered)
+            entry = {"geom": geom.tensor, "num_rendered": rendered, "radii": radii, "img_bytes": int(img.tensor.numel()),
+                     "blend_list": binning.tensor[:max(4 * n_list, 4)].clone(), "ranges": img.tensor[ioff["ranges"]:ioff["ranges"] + 8 * tiles].clone(),
+                     "words": words, "longest_run": int(L.mi_rast_last_longest_run())}
+            entry["bytes"] = sum(int(entry[k].numel()) * entry[k].element_size() for k in ("geom", "blend_list", "ranges", "words", "radii"))
+            cache.insert(ckey, entry)
     else:
         out_color = torch.zeros((channels, H, W), dtype=torch.float32, device=dev)
         out_mask = torch.zeros((1, H, W), dtype=torch.float32, device=dev) if with_mask_depth else None

@@ -299,14 +299,17 @@ def compare_lean_with_full(inp, full: GpuRun, dL=None, dLm=None, full_grads=None
     return lean
 
 
-def compare_float_forward(gpu: GpuRun, fwd: so.ForwardOut, flip_frac=FLIP_FRAC):
+def compare_float_forward(gpu: GpuRun, fwd: so.ForwardOut, flip_frac=FLIP_FRAC, image_state=True):
+    """image_state=False leaves final_T / n_contrib out: where a pixel STOPS (T < 1e-4) is decided on the v_exp_f32 alphas in the
+    product's default exp mode (include/mi_rast.h: MI_RAST_EXACT_EXP), so those two fields are compared under exact_exp."""
     rep = {}
     rep["color"] = assert_close("out_color", gpu.color.cpu().numpy(), fwd.color, flip_frac=flip_frac)
     im = gpu.img_fields()
-    rep["final_T"] = assert_close("final_T", im["final_T"], fwd.state.field(so.F_FINAL_T), flip_frac=flip_frac)
-    nc_g, nc_o = im["n_contrib"], fwd.state.field(so.F_N_CONTRIB)
-    rep["n_contrib_mismatch"] = float((nc_g != nc_o).mean())
-    assert rep["n_contrib_mismatch"] <= max(flip_frac, 1e-4), rep
+    if image_state:
+        rep["final_T"] = assert_close("final_T", im["final_T"], fwd.state.field(so.F_FINAL_T), flip_frac=flip_frac)
+        nc_g, nc_o = im["n_contrib"], fwd.state.field(so.F_N_CONTRIB)
+        rep["n_contrib_mismatch"] = float((nc_g != nc_o).mean())
+        assert rep["n_contrib_mismatch"] <= max(flip_frac, 1e-4), rep
     if gpu.with_mask:
         rep["mask"] = assert_close("out_mask", gpu.out_mask.cpu().numpy(), fwd.mask, flip_frac=flip_frac)
         rep["depth"] = assert_close("out_depth", gpu.out_depth.cpu().numpy(), fwd.depth, flip_frac=flip_frac)

@@ -171,6 +171,12 @@ def test_render_size_follows_the_image_file(tmp_path):
     (tmp_path / "b.jpg").write_bytes(jpg)
     assert colmap_io.image_size_of(str(tmp_path / "a.png")) == (1297, 840)
     assert colmap_io.image_size_of(str(tmp_path / "b.jpg")) == (5187, 3361)
+    # truncated / frame-less files: the ValueError the docstring promises, not a struct.error from a short read
+    whole = (tmp_path / "b.jpg").read_bytes()
+    for k, blob in enumerate((whole[:12], whole[:4], b"\xff\xd8\xff\xd9", b"\xff\xd8\xff\xe0\x00", b"\x89PNG\r\n\x1a\n\x00\x00")):
+        (tmp_path / f"bad{k}.bin").write_bytes(blob)
+        with pytest.raises(ValueError):
+            colmap_io.image_size_of(str(tmp_path / f"bad{k}.bin"))
     c = colmap_io.ColmapCamera(name="a.png", width=5187, height=3361, fovx=1.0, fovy=0.7, R=np.eye(3), T=np.zeros(3))
     assert (colmap_io.to_camera(c).image_width, colmap_io.to_camera(c).image_height) == (1600, 1036)           # camera model, capped
     cam = colmap_io.to_camera(c, image_size=(1297, 840))                                                       # images_4: as loaded

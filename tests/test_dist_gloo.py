@@ -108,6 +108,29 @@ def _worker(rank, world, port, out_dir):
         lo, hi = shard_range(p0.numel(), rank, world)
         assert opt.exp_avg.numel() == hi - lo and opt.step == 3
         assert torch.allclose(mine_p, ref_p.detach(), rtol=1e-5, atol=1e-7), float((mine_p - ref_p.detach()).abs().max())
+        # checkpoint / resume: the gathered state is torch.optim.Adam's state of the parameter, and a fresh ShardedAdam loaded from
+        # EITHER continues like the reference optimizer (FeatureGaussianModel.capture / restore round-trips optimizer.state_dict())
+        sd = opt.state_dict(p0.numel(), shape=(P, C))
+        import copy
+        ref_state = copy.deepcopy(ref_opt.state_dict()["state"][0])   # (the optimizer's own tensors move with its next step)
+        assert float(sd["step"]) == float(ref_state["step"]) == 3.0
+        assert torch.allclose(sd["exp_avg"], ref_state["exp_avg"], rtol=1e-5, atol=1e-9)
+        assert torch.allclose(sd["exp_avg_sq"], ref_state["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+        more = [torch.randn((P, C), generator=g0) * 1e-3 for _ in range(world)]
+        ref_p.grad = sum(more)
+        ref_opt.step()
+        for source in (sd, ref_state):
+            resumed, p_res = ShardedAdam(lr=0.0025), mine_p.clone()
+            resumed.load_state_dict(source)
+            assert resumed.step == 3 and resumed.exp_avg.numel() == hi - lo
+            sharded_update_async(p_res, more[rank].clone(), resumed)
+            assert torch.allclose(p_res, ref_p.detach(), rtol=1e-5, atol=1e-7)
+        with pytest.raises(ValueError):
+            resumed.load_state_dict({"step": 1, "exp_avg": torch.zeros(5), "exp_avg_sq": torch.zeros(5)})   # another tensor's state
+        # average=True: the summed gradient divided by the world size before the update
+        pa, ga = torch.zeros(6), torch.full((6,), float(rank + 1))
+        sharded_update_async(pa, ga, lambda prow, grow, a, b: prow.add_(grow), average=True)
+        assert torch.allclose(pa, torch.full((6,), sum(range(1, world + 1)) / world))
     finally:
         dist.destroy_process_group()
 

@@ -365,6 +365,12 @@ def test_bench_two_ranks_share_the_one_gpu(tmp_path, exchange):
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0 and line["scaling"] == "weak"
     assert "x2" in line["config"]["parallelism"] and line["sustained"]["steps"] >= 4
     assert ("rs-ag" in line["config"]["parallelism"]) == (exchange == "rs-ag")
+    # the line proves who took part: the process group's own view of the ranks and every rank's device (config.comm)
+    comm = line["config"]["comm"]
+    assert comm["nranks"] == 2 and comm["backend"] == "gloo" and comm["exchange"] == exchange and len(comm["devices"]) == 2
+    assert sorted(d["rank"] for d in comm["devices"]) == [0, 1] and len({d["pid"] for d in comm["devices"]}) == 2
+    assert comm["distinct_devices"] == 1            # (both ranks share the one GPU here; N distinct devices on a real node)
+    assert comm["message_bytes"] == Pn * 32 * 4 and isinstance(comm["exposed_ms"], float)
     # the same two views, one after the other, on this process: bench.py's scene, cameras (rank 0 front, rank 1 orbit) and dL
     c = scenes.CONFIGS["cfg3"]
     sc = scenes.scene_of_config("cfg3", seed=0, P=Pn)

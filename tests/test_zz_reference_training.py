@@ -66,7 +66,23 @@ def _write_dataset(root, seed=0):
             f.write(f"{i + 1} {p[0]} {p[1]} {p[2]} {c[0]} {c[1]} {c[2]} 0.5 1 0\n")
 
 
-def test_reference_training_and_rendering_scripts_end_to_end(tmp_path):
+@pytest.mark.parametrize("geometry_cache", [False, True])
+def test_reference_training_and_rendering_scripts_end_to_end(tmp_path, geometry_cache):
+    """geometry_cache=True: the same scripts with the opt-in frozen-geometry reuse switched on (rasterizer.GeometryCache): the
+    training loop revisits its cameras with unchanged geometry -- activation outputs, new tensors per call: hits by content --,
+    and every check below (losses, files, the rendered feature image against the oracle) must hold unchanged."""
+    from seganygaussians_amd import rasterizer as R_
+    cache = None
+    if geometry_cache:
+        cache = R_.enable_geometry_cache(4 << 30)
+        cache.clear()
+    try:
+        _run_reference_scripts(tmp_path, cache)
+    finally:
+        R_.disable_geometry_cache(drop=True)
+
+
+def _run_reference_scripts(tmp_path, cache):
     src, model = str(tmp_path / "data"), str(tmp_path / "model")
     _write_dataset(src)
     os.makedirs(model)
@@ -117,6 +133,9 @@ def test_reference_training_and_rendering_scripts_end_to_end(tmp_path):
         torch.manual_seed(0)
         tr.training(dataset, opt, pipe, 7, [], [], -1)
         S.Scene.save_feature = real_save
+        if cache is not None:   # 20 iterations over NCAM cameras: every camera is revisited, the geometry never changes
+            st = cache.stats()
+            assert st["hits"] >= 20 - 2 * NCAM and st["views"] <= NCAM + 1 and st["hits"] + st["misses"] >= 20, st
         assert len(losses) == 2 and all(math.isfinite(v) for d in losses for v in d.values()), losses
         feats = seen["features"]
         assert torch.isfinite(feats).all() and float(feats.abs().max()) > 2e-2      # moved away from the 1e-2 randn start
