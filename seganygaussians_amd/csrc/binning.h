@@ -135,7 +135,48 @@ constexpr int BIN_MAX_WG = 256;        // workgroups of the count / emit passes 
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_TILES = 22 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 61 KB of hand-off
                                                // arrays must fit in 160 KB; larger images are walked in bands of tile rows
-constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 64;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
+constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 128;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
+
+// ---- bands of tile rows (lean count / emit passes) ----------------------------------------------------------------------------
+// The lean passes walk the image in <= MAX_BANDS bands of band_h tile rows.  A workgroup belongs to ONE band: its LDS counters / cursors
+// cover that band's tiles only, and -- the point -- the entries it stores go to a few hundred tile segments instead of all of them:
+// ~22 consecutive entries per (workgroup, tile) on cfg3 instead of 1.4, which the L2 of the workgroup's XCD merges into whole lines
+// (tools/write_combine_probe.hip: the same 2.93 M eight-byte stores take 16.5 us banded, 30 us with every workgroup storing into every
+// tile's segment; WRITE_SIZE of rounds 2-5 was 64 bytes per entry).  The preprocess pass leaves one bit per band in band_mask[g] and
+// the number of Gaussians per band (r_slots); a band gets workgroups in proportion to that number (band_plan), every workgroup an
+// equal share of the Gaussian INDEX range, of which it picks the Gaussians with its band's bit.
+__host__ __device__ inline bool band_geometry(uint32_t gx, uint32_t gy, uint32_t max_head_words, uint32_t& band_h, uint32_t& nbands)
+{
+    band_h = (gy + 15u) / 16u;
+    if (band_h < 1u) band_h = 1u;
+    while (band_h > 1u && (band_h + 1u) * (gx + 2u) > max_head_words) band_h--;   // (+ 1: the count pass's difference grid has an odd stride >= gx + 1)
+    nbands = (gy + band_h - 1u) / band_h;
+    return nbands <= (uint32_t)MAX_BANDS && (band_h + 1u) * (gx + 2u) <= max_head_words;
+}
+
+// s_plan[b] = first workgroup of band b, s_plan[nbands] = workgroups in use (<= nwg): one workgroup per band plus the rest in
+// proportion to the bands' Gaussian counts.  Call from one whole wave; every kernel that needs the plan recomputes it from the same
+// counters with this same code.
+__device__ __forceinline__ void band_plan(const int* __restrict__ r_slots, uint32_t nbands, uint32_t nwg, uint32_t* s_plan, int lane)
+{
+    uint32_t cnt = 0;
+    if ((uint32_t)lane < nbands)
+        for (int k = 0; k < R_SLOTS; k++) cnt += (uint32_t)r_slots[k * R_SLOT_STRIDE + R_SLOT_BANDS + lane];
+    uint32_t total = cnt;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) total += (uint32_t)__shfl_xor((int)total, o, 64);
+    const uint32_t avail = nwg > nbands ? nwg - nbands : 0u;
+    uint32_t n = (uint32_t)lane < nbands ? 1u + (total ? (uint32_t)(((uint64_t)cnt * avail) / total) : 0u) : 0u;
+    if (nwg < nbands) n = (uint32_t)lane < nwg ? 1u : 0u;   // (never launched so: the host gives at least one workgroup per band)
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if ((uint32_t)lane < nbands) s_plan[lane] = incl - n;
+    if ((uint32_t)lane == nbands) s_plan[nbands] = incl;   // (lanes >= nbands hold the grand total: n = 0 there)
+}
 
 // Words behind the R partial sums of the image buffer's num_rendered field (mi_rast.hip: ImgPtrs)
 constexpr int NR_TOTAL = 0, NR_LONGEST = 1, NR_VERIFY = 2, NR_KEY_BITS = 3, NR_RUN_BOUNDS = 4;
@@ -146,7 +187,11 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
                                                            uint32_t* __restrict__ zero_a = nullptr, uint32_t* __restrict__ zero_b = nullptr,
                                                            uint32_t* __restrict__ run_bounds = nullptr /* [9]: the blend kernels' XCD runs
                                                                (common.h): equal tile counts, or equal MODELLED work when run_cap > 0 */,
-                                                           uint32_t run_cap = 0, uint32_t run_fix = 0)
+                                                           uint32_t run_cap = 0, uint32_t run_fix = 0,
+                                                           uint32_t* __restrict__ band_partial = nullptr /* lean lists: [workgroup][tile of its
+                                                               band] counts of the banded count pass; the scan over a tile's workgroups happens HERE
+                                                               (in place: exclusive prefix), tile_total is not read */,
+                                                           uint32_t gx = 0, uint32_t band_h = 0, uint32_t nbands = 0, uint32_t nwg_plan = 0)
 {
     // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
     // one workgroup scan joins the pieces, and the ranges leave coalesced again.
@@ -166,8 +211,11 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
     const bool weighted = run_bounds != nullptr && run_cap > 0u && ntiles_all <= BIN_MAX_TILES_TOTAL;   // (one segment)
     __shared__ uint32_t s_maxcount;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t s_plan[MAX_BANDS + 1];
+    if (band_partial != nullptr && wave == 0) band_plan(r_slots, nbands, nwg_plan, s_plan, lane);
     if (tid < 9) s_bound[tid] = xcd_run_start((uint32_t)tid, (uint32_t)ntiles_all);   // equal tile counts unless the model says otherwise
     if (tid == 0) s_maxcount = 0;
+    if (band_partial != nullptr) __syncthreads();
     if (wave == 15 && r_slots != nullptr) {   // (a wave that has the least to do below)
         uint32_t inv_min = (uint32_t)r_slots[(lane % R_SLOTS) * R_SLOT_STRIDE + 1];
         uint32_t mx = (uint32_t)r_slots[(lane % R_SLOTS) * R_SLOT_STRIDE + 2];
@@ -183,7 +231,23 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
     uint32_t carry = 0;   // entries in front of the segment (the same in every thread)
     for (int seg0 = 0; seg0 < ntiles_all; seg0 += BIN_MAX_TILES_TOTAL) {
         const int ntiles = min(BIN_MAX_TILES_TOTAL, ntiles_all - seg0);
-        for (int i = tid; i < ntiles; i += 1024) s_val[i] = tile_total[seg0 + i];
+        if (band_partial != nullptr) {
+            // a tile's entries come from the workgroups of its band: total = their sum, and every workgroup's share is replaced by
+            // what lies in front of it inside the tile's segment (0.6 MB in all on a 1080p view)
+            const uint32_t btm = band_h * gx;
+            for (int i = tid; i < ntiles; i += 1024) {
+                const uint32_t t = (uint32_t)(seg0 + i), b = (t / gx) / band_h, tl = t - b * btm;
+                uint32_t run = 0;
+                for (uint32_t w = s_plan[b]; w < s_plan[b + 1]; w++) {
+                    const uint32_t c = band_partial[(size_t)w * btm + tl];
+                    band_partial[(size_t)w * btm + tl] = run;
+                    run += c;
+                }
+                s_val[i] = run;
+            }
+        } else {
+            for (int i = tid; i < ntiles; i += 1024) s_val[i] = tile_total[seg0 + i];
+        }
         __syncthreads();
         const int per = (ntiles + 1023) / 1024;
         const int i0 = min(ntiles, tid * per), i1 = min(ntiles, i0 + per);
@@ -582,8 +646,10 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
 // on cfg3, ~1 us per phase whatever it computed).  Hand-offs between the lanes of a wave go through wave-private LDS words;
 // LDS operations of one wave execute in program order, the wavefront fences keep the compiler from reordering them.
 // Measured on cfg3: 2.27 M (Gaussian, row) items, 2.93 M entries.
-constexpr int BW_WORDS = 64 * 16;  // LDS words per wave: prefix, rect, depth bits, owner scratch, two float4 of span constants + mean; emit: span prefix, two bands' columns, span origin
+constexpr int BW_WORDS = 64 * 22;  // LDS words per wave: prefix, rect, depth bits, id, owner scratch, two float4 of span constants + mean, the id queue (5 x 64); emit: span prefix, two bands' columns, span origin
+constexpr int SPAN_MASK_CHUNKS = 4;   // band-mask chunks (64 Gaussians each) a wave takes from its workgroup's counter at a time
 __host__ __device__ constexpr size_t span_lds_bytes(size_t head_words) { return (((head_words + 3) & ~(size_t)3) + 4 + 16 * BW_WORDS) * sizeof(uint32_t); }
+constexpr uint32_t SPAN_MAX_HEAD_WORDS = 40 * 1024 - 16 * BW_WORDS - 64;   // counters / cursors of one band: what is left of 160 KB
 
 // Hand-off point between the lanes of ONE wave through LDS: LDS operations of a wave execute in program order, so no wait is needed --
 // but the compiler must neither move LDS accesses across this point nor forward a lane's own store to its later load (another
@@ -618,25 +684,36 @@ __device__ __forceinline__ uint32_t wave_owner(uint32_t* scratch /* [64] wave-pr
 
 template <bool EMIT>
 __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* __restrict__ index_rec,
-                                                         const uint32_t* __restrict__ depth_key,
+                                                         const uint32_t* __restrict__ depth_key, const uint32_t* __restrict__ band_mask,
                                                          uint32_t* __restrict__ partial, const uint2* __restrict__ ranges,
                                                          uint2* __restrict__ entries, uint32_t gx, uint32_t gy_all,
-                                                         uint32_t by0, uint32_t by1, const int* __restrict__ r_slots,
+                                                         uint32_t band_h, uint32_t nbands, const int* __restrict__ r_slots,
                                                          int* __restrict__ host_r, int ablate)
 {
     // COUNT: s_dyn = difference grid [band rows][stride] (ints), then the chunk counter and the waves' hand-off words
     // EMIT : s_dyn = cursors [band tiles], then the same
     extern __shared__ uint32_t s_dyn[];
+    __shared__ uint32_t s_plan[MAX_BANDS + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The first kernel behind the preprocess pass hands the partial sums of R to the host: plain stores into its pinned buffer
+    // (a copy command of 8 KB costs a 5-us blit kernel on the stream); the event behind this kernel tells the host they are there.
+    if (!EMIT && host_r != nullptr && blockIdx.x == 0 && tid < R_SLOTS) host_r[tid * R_SLOT_STRIDE] = r_slots[tid * R_SLOT_STRIDE];
+    if (wave == 0) band_plan(r_slots, nbands, gridDim.x, s_plan, lane);
+    __syncthreads();
+    if (blockIdx.x >= s_plan[nbands]) return;   // (workgroups the plan leaves over)
+    uint32_t band = 0;
+    while (band + 1u < nbands && s_plan[band + 1u] <= blockIdx.x) band++;
+    const uint32_t nsub = s_plan[band + 1u] - s_plan[band], sub = blockIdx.x - s_plan[band];
+    const uint32_t by0 = band * band_h, by1 = min(gy_all, by0 + band_h);
+    const uint32_t band_bit = 1u << band;
     const uint32_t gy = by1 - by0;
     const int stride = count_grid_stride(gx);
     const int ntiles = (int)(gx * gy);
     const int tile0 = (int)(gx * by0);
-    const int ntiles_all = (int)(gx * gy_all);
     const int head = EMIT ? ((ntiles + 3) & ~3) : (((int)gy * stride + 3) & ~3);
     uint32_t* s_cnt = s_dyn;
     int* s_grid = reinterpret_cast<int*>(s_dyn);
-    uint32_t* s_next = s_dyn + head;   // [4]: next chunk of the slice
+    uint32_t* s_next = s_dyn + head;   // [4]: next group of mask chunks of this workgroup's share
     uint32_t* wb = s_dyn + head + 4 + wave * BW_WORDS;
     uint32_t* w_pre = wb;              // inclusive prefix of the lanes' row counts
     uint32_t* w_rect = wb + 64;        // clip columns x0 | x1 << 10, first row << 21
@@ -648,46 +725,82 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
     uint32_t* w_q0 = wb + 832;         //   upper band's columns lo | hi << 11, owner lane << 22
     uint32_t* w_q1 = wb + 896;         //   lower band's columns lo | hi << 11
     uint32_t* w_sx = wb + 960;         //   first tile column | tile row << 10
-    // The first kernel behind the preprocess pass hands the partial sums of R to the host: plain stores into its pinned buffer
-    // (a copy command of 8 KB costs a 5-us blit kernel on the stream); the event behind this kernel tells the host they are there.
-    if (!EMIT && host_r != nullptr && blockIdx.x == 0 && tid < R_SLOTS) host_r[tid * R_SLOT_STRIDE] = r_slots[tid * R_SLOT_STRIDE];
-    uint32_t* my_partial = partial + (size_t)slice_row(blockIdx.x, gridDim.x) * ntiles_all + tile0;
+    uint32_t* w_id = wb + 1024;        // Gaussian id of the lane's record
+    uint32_t* w_queue = wb + 1088;     // [192]: ids of this band's Gaussians, in index order, waiting for a full chunk
+    uint32_t* my_partial = partial + (size_t)blockIdx.x * (band_h * gx);   // [workgroup][tile of its band]
     if (EMIT) {
         for (int t = tid; t < ntiles; t += 1024) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
     } else {
         for (int c = tid; c < (int)gy * stride; c += 1024) s_grid[c] = 0;
     }
-    if (tid == 0) s_next[0] = 16u;   // (the first 16 chunks of the slice go to the waves by their number)
+    if (tid == 0) s_next[0] = 0u;
     __syncthreads();
-    const int nwg = (int)gridDim.x;
-    const int nchunks = (P + 63) / 64;
-    // chunk j of this slice is chunk j * nwg + blockIdx.x of the view
-    const int nloc = (int)blockIdx.x < nchunks ? (nchunks - (int)blockIdx.x + nwg - 1) / nwg : 0;
-    int j = wave;
-    uint32_t nkey = 0xFFFFFFFFu;
-    BlendRec nrec;
-    {
-        const int i = min((j * nwg + (int)blockIdx.x) * 64 + lane, P - 1);
-        nrec = index_rec[i];
-        nkey = depth_key[i];
-    }
-    while (j < nloc) {
-        const int chunk = j * nwg + (int)blockIdx.x;
-        const int i = chunk * 64 + lane;
+    // This workgroup's share of the Gaussians: mask chunks (64 consecutive indices) [c0, c1) of the view's, an equal part of the
+    // index range for each of the band's workgroups.  A wave takes SPAN_MASK_CHUNKS of them at a time from the LDS counter, keeps
+    // the ids whose band bit is set in a wave-private queue, and walks a chunk of 64 queued Gaussians whenever one is full.
+    const uint32_t nchunks_all = ((uint32_t)P + 63u) / 64u;
+    const uint32_t mc0 = (uint32_t)(((uint64_t)sub * nchunks_all) / nsub), mc1 = (uint32_t)(((uint64_t)(sub + 1u) * nchunks_all) / nsub);
+    uint32_t qn = 0;          // ids in the queue (wave-uniform)
+    // group of mask chunks requested ahead: its first chunk (>= mc1: none left) and the lanes' mask words, in flight while the
+    // previous group is sifted and the previous chunk of Gaussians is walked (unconditional loads, clamped: a conditionally assigned
+    // load result is waited for on the spot; validity is applied where the words are used)
+    uint32_t g_next;
+    uint32_t m_next[SPAN_MASK_CHUNKS];
+    auto request_masks = [&]() __attribute__((always_inline)) {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(s_next, (uint32_t)SPAN_MASK_CHUNKS);
+        g_next = mc0 + (uint32_t)__builtin_amdgcn_readfirstlane(g);
+#pragma unroll
+        for (int k = 0; k < SPAN_MASK_CHUNKS; k++)
+            m_next[k] = band_mask[min((g_next + (uint32_t)k) * 64u + (uint32_t)lane, (uint32_t)P - 1u)];
+    };
+    // next chunk of <= 64 queued Gaussians -> id (0xFFFFFFFF: lane without one); false: this workgroup's share is exhausted
+    auto take_chunk = [&](uint32_t& id) __attribute__((always_inline)) -> bool {
+        while (qn < 64u && g_next < mc1) {
+            const uint32_t g = g_next;
+            uint32_t m[SPAN_MASK_CHUNKS];
+#pragma unroll
+            for (int k = 0; k < SPAN_MASK_CHUNKS; k++) m[k] = m_next[k];
+            request_masks();
+#pragma unroll
+            for (int k = 0; k < SPAN_MASK_CHUNKS; k++) {
+                const uint32_t i = (g + (uint32_t)k) * 64u + (uint32_t)lane;
+                const bool mine = g + (uint32_t)k < mc1 && i < (uint32_t)P && (m[k] & band_bit) != 0u;
+                const uint64_t bal = ballot64(mine);
+                if (mine) w_queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = i;
+                qn += (uint32_t)__builtin_popcountll(bal);   // (<= 63 + 4 x 64: the queue holds 5 x 64 words)
+            }
+        }
+        if (qn == 0u) return false;
+        wave_lds_fence();
+        const uint32_t take = min(qn, 64u);
+        id = (uint32_t)lane < take ? w_queue[lane] : 0xFFFFFFFFu;
+        uint32_t rest[4];   // the rest of the queue moves to its front
+#pragma unroll
+        for (int k = 0; k < 4; k++) rest[k] = w_queue[64 + 64 * k + lane];
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 4; k++) w_queue[64 * k + lane] = rest[k];
+        wave_lds_fence();
+        qn -= take;
+        return true;
+    };
+    request_masks();
+    uint32_t nid = 0xFFFFFFFFu;
+    bool have = take_chunk(nid);
+    BlendRec nrec = index_rec[nid == 0xFFFFFFFFu ? 0u : nid];
+    uint32_t nkey = depth_key[nid == 0xFFFFFFFFu ? 0u : nid];
+    while (have) {
+        const uint32_t id = nid;
         const BlendRec rec = nrec;
         const uint32_t key = nkey;
-        // next chunk of the slice: taken now, its records requested before this chunk's items are walked (unconditional loads,
-        // index clamped: a conditionally assigned load result is waited for on the spot)
-        uint32_t jn = 0;
-        if (lane == 0) jn = atomicAdd(s_next, 1u);
-        j = (int)__builtin_amdgcn_readfirstlane(jn);
-        {
-            const int in = min((min(j, nloc > 0 ? nloc - 1 : 0) * nwg + (int)blockIdx.x) * 64 + lane, P - 1);
-            nrec = index_rec[in];
-            nkey = depth_key[in];
-        }
+        // the next chunk's ids, and its records requested before this chunk's items are walked
+        nid = 0xFFFFFFFFu;
+        have = take_chunk(nid);
+        nrec = index_rec[nid == 0xFFFFFFFFu ? 0u : nid];
+        nkey = depth_key[nid == 0xFFFFFFFFu ? 0u : nid];
         uint32_t h = 0;
-        if (i < P && key != 0xFFFFFFFFu) {   // visible: radius > 0, record written (geometry.h)
+        if (id != 0xFFFFFFFFu) {   // visible (its band bit was set): radius > 0, record written (geometry.h)
             const int rad = (int)rec.pm;
             uint2 rmin, rmax;
             getRect(rec.xy.x, rec.xy.y, rad, rmin, rmax, gx, gy_all);
@@ -701,7 +814,10 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
                 w_c0[lane] = make_float4(pre.B, pre.rcpA, pre.twotauA, pre.det);
                 w_c1[lane] = make_float4(pre.cull ? pre.ey : -1.0f, pre.ystar, rec.xy.x, rec.xy.y);
                 w_rect[lane] = rmin.x | (rmax.x << 10) | (rmin.y << 21);
-                if (EMIT) w_key[lane] = key;
+                if (EMIT) {
+                    w_key[lane] = key;
+                    w_id[lane] = id;
+                }
             }
         }
         const uint32_t hincl = wave_inclusive_scan_dpp(h);
@@ -775,7 +891,7 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
                         if (qmask != 0u && !MI_ABLATE(1 << 17)) {
                             const uint32_t gg = q0 >> 22;
                             const uint32_t slot = atomicAdd(&s_cnt[(ty - by0) * gx + tx], 1u);
-                            if (!MI_ABLATE(1 << 19)) entries[slot] = make_uint2(w_key[gg], (uint32_t)(chunk * 64 + (int)gg) | (qmask << ID_BITS));
+                            if (!MI_ABLATE(1 << 19)) entries[slot] = make_uint2(w_key[gg], w_id[gg] | (qmask << ID_BITS));
                         }
                     }
                 }
@@ -786,7 +902,7 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
     }
     if (!EMIT) {
         __syncthreads();
-        // prefix along x: one wave per row, 64 cells at a time with a carry -> the per-tile counts of this slice
+        // prefix along x: one wave per row, 64 cells at a time with a carry -> the per-tile counts of this workgroup
         for (int y = wave; y < (int)gy; y += 16) {
             int carry = 0;
             for (int x0 = 0; x0 < (int)gx; x0 += 64) {
@@ -1024,21 +1140,19 @@ __global__ void __launch_bounds__(256) verify_entries_kernel(uint32_t ntiles, co
 template <int M>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v)
 {
-    auto dpp = [](uint32_t old, uint32_t src, auto ctrl, auto bank) {
-        return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, decltype(ctrl)::value, 0xF, decltype(bank)::value, false);
-    };
-    using std::integral_constant;
-    if constexpr (M == 1) return dpp(0u, v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{});         // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) return dpp(0u, v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{});    // quad_perm [2,3,0,1]
-    else if constexpr (M == 3) return dpp(0u, v, integral_constant<int, 0x1B>{}, integral_constant<int, 0xF>{});    // quad_perm [3,2,1,0]
-    else if constexpr (M == 7) return dpp(0u, v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{});   // row_half_mirror
-    else if constexpr (M == 15) return dpp(0u, v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{});  // row_mirror
+    // (full row / bank masks, every lane has a source: v_mov_b32_dpp without an `old` operand -- update_dpp(0, ...) costs a
+    // v_mov_b32 0 in front of every move)
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);         // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);    // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);  // row_mirror
     else if constexpr (M == 4) {   // lanes 0-3 / 8-11 of a row take lane + 4 (row_shl), the others lane - 4 (row_shr)
-        const uint32_t t = dpp(0u, v, integral_constant<int, 0x104>{}, integral_constant<int, 0x5>{});
-        return dpp(t, v, integral_constant<int, 0x114>{}, integral_constant<int, 0xA>{});
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)v, 0x114, 0xF, 0xA, false);
     } else if constexpr (M == 8) {
-        const uint32_t t = dpp(0u, v, integral_constant<int, 0x108>{}, integral_constant<int, 0x3>{});
-        return dpp(t, v, integral_constant<int, 0x118>{}, integral_constant<int, 0xC>{});
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0x3, false);
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)v, 0x118, 0xF, 0xC, false);
     } else if constexpr (M == 16 || M == 31) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);   // bit mode: lane ^ M inside 32 lanes
     else return (uint32_t)__shfl_xor((int)v, M, 64);   // 32, 63
 }
@@ -1051,10 +1165,10 @@ __device__ __forceinline__ double lane_xor64(double v)
 }
 __device__ __forceinline__ void minmax64(double& lo, double& hi)   // (inline asm: no canonicalisation of the operands in front of it)
 {
-    double mn, mx;
-    asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(mn), "=&v"(mx) : "v"(lo), "v"(hi));
+    double mn;
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(lo), "v"(hi));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(lo), "v"(hi));   // (may overwrite an operand in place: no copies around the pair)
     lo = mn;
-    hi = mx;
 }
 
 // one step of stage K: FLIP -- partner i ^ (K - 1) -- or distance J
@@ -1065,14 +1179,14 @@ __device__ __forceinline__ void bitonic_step(double (&a)[EPL], int lane)
         // i ^ (K - 1) = (lane ^ (K / EPL - 1)) * EPL + (EPL - 1 - r): the mirrored register of the mirrored lane
         constexpr int M = K / EPL - 1;
         const bool lower = (lane & ((M + 1) >> 1)) == 0;
-        double o[EPL];
 #pragma unroll
-        for (int r = 0; r < EPL; r++) o[r] = lane_xor64<M>(a[EPL - 1 - r]);
-#pragma unroll
-        for (int r = 0; r < EPL; r++) {
-            double x = a[r], y = o[r];
-            minmax64(x, y);
-            a[r] = lower ? x : y;
+        for (int r = 0; r < EPL / 2; r++) {   // registers r and EPL - 1 - r trade places with the partner lane's: two temporaries at a time
+            double x0 = a[r], y0 = lane_xor64<M>(a[EPL - 1 - r]);
+            double x1 = a[EPL - 1 - r], y1 = lane_xor64<M>(a[r]);
+            minmax64(x0, y0);
+            minmax64(x1, y1);
+            a[r] = lower ? x0 : y0;
+            a[EPL - 1 - r] = lower ? x1 : y1;
         }
     } else if constexpr (!FLIP && J >= EPL) {
         constexpr int M = J / EPL;
@@ -1125,10 +1239,10 @@ __device__ __forceinline__ void tile_sort_in_wave(const uint2* __restrict__ seg,
     }
 }
 
-constexpr int TILE_SORT_WAVE_MAX = 2048;   // longest list the wave kernels order (EPL = 32); longer ones: tile_sort_kernel below
-// LONG = false: lists of 1 .. 1024 entries (EPL = 4 / 8 / 16: 48 VGPRs); LONG = true: 1025 .. 2048 (EPL = 32), launched only when a
-// tile needs it -- one kernel for both would run the short lists at the long ones' register count.
-template <bool LONG>
+constexpr int TILE_SORT_WAVE_MAX = 4096;   // longest list the wave kernels order (EPL = 64); longer ones: tile_sort_kernel below
+// CLASS 0: lists of 1 .. 1024 entries (EPL = 4 / 8 / 16: 52 VGPRs); 1: 1025 .. 2048 (EPL = 32); 2: 2049 .. 4096 (EPL = 64) -- the
+// longer classes are launched only when a tile needs them: one kernel for all would run the short lists at the long ones' register count.
+template <int CLASS>
 __global__ void __launch_bounds__(256) tile_sort_wave_kernel(uint32_t ntiles, const uint2* __restrict__ ranges,
                                                               const uint2* __restrict__ entries, uint32_t* __restrict__ blend_list)
 {
@@ -1139,8 +1253,10 @@ __global__ void __launch_bounds__(256) tile_sort_wave_kernel(uint32_t ntiles, co
     const int n = (int)(range.y - range.x);
     const uint2* seg = entries + range.x;
     uint32_t* out = blend_list + range.x;
-    if constexpr (LONG) {
-        if (n > 1024 && n <= TILE_SORT_WAVE_MAX) tile_sort_in_wave<32>(seg, n, out, lane);
+    if constexpr (CLASS == 2) {
+        if (n > 2048 && n <= 4096) tile_sort_in_wave<64>(seg, n, out, lane);
+    } else if constexpr (CLASS == 1) {
+        if (n > 1024 && n <= 2048) tile_sort_in_wave<32>(seg, n, out, lane);
     } else {
         if (n == 0 || n > 1024) return;
         if (n <= 256) tile_sort_in_wave<4>(seg, n, out, lane);

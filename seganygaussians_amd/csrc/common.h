@@ -23,7 +23,9 @@
 namespace mirast {
 
 constexpr int R_SLOTS = 64;        // partial sums of R, one per 128-byte line
-constexpr int R_SLOT_STRIDE = 32;  // ints
+constexpr int R_SLOT_STRIDE = 32;  // ints: [0] R, [1] max of ~depth key, [2] max depth key, [R_SLOT_BANDS + b] Gaussians touching band b
+constexpr int R_SLOT_BANDS = 4;
+constexpr int MAX_BANDS = 24;      // bands of tile rows of the lean count / emit passes (binning.h); one bit per band in band_mask
 
 
 constexpr int TILE_X = 16;  // CF/cuda_rasterizer/config_contrastive_f.h:16 -- part of the integer contract

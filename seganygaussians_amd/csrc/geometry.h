@@ -121,9 +121,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int* __restrict__ radii, float2* __restrict__ points_xy_image, float* __restrict__ depths,
     float* __restrict__ cov3Ds, float* __restrict__ rgb, float4* __restrict__ conic_opacity,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, BlendRec* __restrict__ index_rec,
-    int* __restrict__ r_slots, int prefiltered, int* __restrict__ culled_prefiltered)
+    int* __restrict__ r_slots, int prefiltered, int* __restrict__ culled_prefiltered, uint32_t* __restrict__ band_mask,
+    uint32_t band_h, uint32_t nbands)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_band[MAX_BANDS];   // Gaussians of this workgroup per band of tile rows (binning.h: lean count / emit passes)
+    if (threadIdx.x < MAX_BANDS) s_band[threadIdx.x] = 0u;
     // SH colours (forward.cu:23-74 reads 3 M floats per Gaussian, 192 bytes at degree 3): a thread walking its own row makes
     // every load instruction of the wave touch 64 rows 192 bytes apart.  The workgroup's rows are one contiguous block of
     // memory: staged into LDS with coalesced 16-byte loads (culled Gaussians included: 25 % more bytes, all of them streamed),
@@ -212,11 +215,24 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             index_rec[idx] = rec;
         }
     } while (0);
+    // bands of band_h tile rows the reference rect reaches (a superset of the rows the lean lists keep): one bit per band for the
+    // count / emit passes, which walk the image band by band, and this workgroup's count per band for their work split
+    uint32_t my_bands = 0u;
+    if (my_radii > 0 && rect_max.y > rect_min.y && rect_max.x > rect_min.x) {
+        const uint32_t b0 = rect_min.y / band_h, b1 = (rect_max.y - 1u) / band_h;
+        my_bands = (b1 >= 31u ? 0xFFFFFFFFu : ((2u << b1) - 1u)) & ~((1u << b0) - 1u);
+    }
     if (idx < P) {
         radii[idx] = my_radii;
         tiles_touched[idx] = my_tiles;
         depth_key[idx] = my_key;
+        band_mask[idx] = my_bands;
     }
+    __syncthreads();   // (s_band zeroed; the SH staging barrier above is conditional)
+    for (uint32_t m = my_bands; m != 0u; m &= m - 1u) atomicAdd(&s_band[__builtin_ctz(m)], 1u);
+    __syncthreads();
+    if (threadIdx.x < nbands && s_band[threadIdx.x] != 0u)
+        atomicAdd(&r_slots[(blockIdx.x % R_SLOTS) * R_SLOT_STRIDE + R_SLOT_BANDS + threadIdx.x], (int)s_band[threadIdx.x]);
     // R = sum of tiles_touched over the Gaussians that later stages treat as visible (what InclusiveSum's last
     // element is in the reference, rasterizer_impl.cu:277-281), and the range of their depth keys (depth_sort.h).
     // Three atomics per wave, spread over R_SLOTS lines: same-line L2 atomics serialise at ~22 ns each.

@@ -191,6 +191,7 @@ struct GeomPtrs {
     uint32_t* depth_key;
     BlendRec* index_rec;  // [P] {mean, id, radius, conic + opacity} in index order (written by the preprocess pass for visible Gaussians)
     int* cull_counter;    // one word: Gaussians culled although `prefiltered` was set
+    uint32_t* band_mask;  // [P] one bit per band of tile rows the Gaussian's rect reaches (binning.h: lean count / emit passes)
     float* bwd_pack;  // [P,8] packed per-Gaussian field gradients (backward scratch)
 };
 struct ImgPtrs {
@@ -228,6 +229,7 @@ GeomPtrs geom_from(char* base, int P)
     g.depth_key = (uint32_t*)(base + off[MI_GEOM_DEPTH_KEY]);
     g.index_rec = (BlendRec*)(base + off[MI_GEOM_INDEX_REC]);
     g.cull_counter = (int*)(base + off[MI_GEOM_CULL_COUNTER]);
+    g.band_mask = (uint32_t*)(base + off[MI_GEOM_BAND_MASK]);
     g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
     return g;
 }
@@ -354,10 +356,14 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     if (P >= (1 << ID_BITS)) return fail(MI_RAST_ERR_INVALID, "more than 2^28 Gaussians");
     if (vp.grid_x > 1023u || vp.grid_y > 2047u)
         return fail(MI_RAST_ERR_INVALID, "image too large: more than 1023 tiles across or 2047 tiles down");
-    // images with more tiles than one launch of the count / emit passes has LDS counters for are walked in bands of tile rows
-    // (grid_x + 2: the count passes keep band_rows (+ 1) rows of an odd stride >= grid_x + 1 in the same LDS budget)
+    // FULL lists (parity tests): images with more tiles than one launch of the full count / emit passes has LDS counters for are walked
+    // in bands of tile rows by the host (grid_x + 2: the count pass keeps band_rows (+ 1) rows of an odd stride >= grid_x + 1)
     const uint32_t band_rows = std::min<uint32_t>(vp.grid_y, std::max<uint32_t>(1u, (uint32_t)BIN_MAX_TILES / (vp.grid_x + 2u) - 1u));
     const uint32_t nbands = (vp.grid_y + band_rows - 1) / band_rows;
+    // LEAN lists: <= MAX_BANDS device-side bands of lean_band_h tile rows, every workgroup of the count / emit passes in one of them
+    uint32_t lean_band_h = 1, lean_nbands = 1;
+    if (!band_geometry(vp.grid_x, vp.grid_y, SPAN_MAX_HEAD_WORDS, lean_band_h, lean_nbands))
+        return fail(MI_RAST_ERR_INVALID, "image too large for the banded binning passes (more than 24 bands of tile rows at this width)");
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
         HIP_TRY(hipMemsetAsync(img.num_rendered, 0, R_SLOTS * R_SLOT_STRIDE * sizeof(int), stream));
@@ -367,7 +373,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), sh_lds, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
-                           geom.depth_key, geom.index_rec, img.num_rendered, prefiltered, cull_counter);
+                           geom.depth_key, geom.index_rec, img.num_rendered, prefiltered, cull_counter, geom.band_mask, lean_band_h, lean_nbands);
     }
     STAGE_CHECK("preprocess");
     if (prefiltered) {
@@ -384,8 +390,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_ranks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             HIP_TRY(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            // (160 KB per workgroup less the kernels' static words: the band plan)
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            HIP_TRY(hipFuncSetAttribute((const void*)bin_spans_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
             HIP_TRY(hipFuncSetAttribute((const void*)tile_ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (BIN_MAX_TILES_TOTAL + 1) * (int)sizeof(uint32_t)));
             HIP_TRY(hipFuncSetAttribute((const void*)run_bounds_from_walks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -400,8 +407,9 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     // `debug` flag or MI_RAST_FULL_LISTS -- ; otherwise only the overlaps that pass the cull are listed.
     const bool nocull = (flags & MI_RAST_NO_CULL) != 0;
     const bool full = debug != 0 || nocull || (flags & MI_RAST_FULL_LISTS) != 0;
-    // <= 256 workgroups of 1024 threads, each a slice of the Gaussians (64-index chunks dealt round robin)
-    int nwg = bin_workgroups(P);
+    // full lists: <= 256 workgroups of 1024 threads, each a slice of the Gaussians (64-index chunks dealt round robin); lean lists:
+    // workgroups dealt to the bands in proportion to the bands' Gaussian counts (binning.h: band_plan), at least one per band
+    int nwg = full ? bin_workgroups(P) : std::min(BIN_MAX_WG, (int)lean_nbands + (P + 1023) / 1024);
 #ifdef MI_RAST_PROFILING
     if (ablate_env("MI_RAST_NWG") > 0) nwg = std::min(nwg, ablate_env("MI_RAST_NWG"));
 #endif
@@ -411,30 +419,32 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         // count pass over slices, scan over (tile, slice), scan over tiles -> ranges (binning.h)
         StageTimer t(stream, MI_STAGE_TILE_SCAN);
         const size_t cnt_lds = (size_t)(band_rows + 1) * count_grid_stride(vp.grid_x) * sizeof(int);
-        for (uint32_t b = 0; b < nbands; b++) {
+        for (uint32_t b = 0; full && b < nbands; b++) {
             const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
             if (full)
                 hipLaunchKernelGGL(bin_count_kernel, dim3(nwg), dim3(BIN_THREADS), cnt_lds, stream, P, geom.index_rec, geom.depth_key,
                                    img.tile_count, vp.grid_x, vp.grid_y, by0, by1, (const int*)img.num_rendered,
                                    b == 0 ? g_host_sync.pinned_dev : (int*)nullptr);
-            else
-                hipLaunchKernelGGL(bin_spans_kernel<false>, dim3(nwg), dim3(1024),
-                                   span_lds_bytes((size_t)(by1 - by0) * count_grid_stride(vp.grid_x)), stream, P, geom.index_rec,
-                                   geom.depth_key, img.tile_count, (const uint2*)nullptr, (uint2*)nullptr, vp.grid_x, vp.grid_y, by0, by1,
-                                   (const int*)img.num_rendered, b == 0 ? g_host_sync.pinned_dev : (int*)nullptr, g_ablate_fwd);
         }
+        if (!full)
+            hipLaunchKernelGGL(bin_spans_kernel<false>, dim3(nwg), dim3(1024), span_lds_bytes((size_t)lean_band_h * count_grid_stride(vp.grid_x)),
+                               stream, P, geom.index_rec, geom.depth_key, geom.band_mask, img.tile_count, (const uint2*)nullptr, (uint2*)nullptr,
+                               vp.grid_x, vp.grid_y, lean_band_h, lean_nbands, (const int*)img.num_rendered, g_host_sync.pinned_dev, g_ablate_fwd);
         HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
         // (one launch for both scans -- every workgroup scans its tiles over the slices, the last one to finish scans the totals
         // behind a device-scope counter and agent-scope fences -- was built and measured in round 4: tile scan 0.058 -> 0.060 ms
         // on cfg3; the fences and the serial tail inside the kernel cost more than the launch they save)
-        hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
-                           img.tile_count, img.tile_cursor);
+        // full lists: scan over (tile, slice) here; lean lists: the range scan below sums a tile's workgroups itself (0.6 MB)
+        if (full)
+            hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
+                               img.tile_count, img.tile_cursor);
         const uint32_t run_cap = !(flags & MI_RAST_EQUAL_RUNS) ? (uint32_t)std::max(0, knob("MI_RAST_RUN_CAP", RUN_MODEL_CAP)) : 0u;
         const uint32_t run_fix = (uint32_t)std::max(0, knob("MI_RAST_RUN_FIX", RUN_MODEL_FIX));
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024),
                            ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor,
                            img.ranges, img.num_rendered + R_SLOTS * R_SLOT_STRIDE, (const int*)img.num_rendered,
-                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds, run_cap, run_fix);
+                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds, run_cap, run_fix,
+                           full ? (uint32_t*)nullptr : img.tile_count, vp.grid_x, lean_band_h, lean_nbands, (uint32_t)nwg);
     }
     STAGE_CHECK("tile scan");
     HIP_TRY(hipEventRecord(g_host_sync.ev2, stream));
@@ -462,7 +472,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         {
             StageTimer t(stream, MI_STAGE_EMIT);
             const size_t emit_lds = bin_lds + 8 * 1024 * sizeof(uint32_t);
-            for (uint32_t b = 0; b < nbands; b++) {
+            for (uint32_t b = 0; full && b < nbands; b++) {
                 const uint32_t by0 = b * band_rows, by1 = std::min(vp.grid_y, by0 + band_rows);
                 if (nocull)
                     hipLaunchKernelGGL(bin_ranks_kernel<true>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.index_rec, geom.depth_key,
@@ -470,11 +480,11 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                 else if (full)
                     hipLaunchKernelGGL(bin_ranks_kernel<false>, dim3(nwg), dim3(BIN_THREADS), emit_lds, stream, P, geom.index_rec, geom.depth_key,
                                        img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1);
-                else
-                    hipLaunchKernelGGL(bin_spans_kernel<true>, dim3(nwg), dim3(1024), span_lds_bytes((size_t)(by1 - by0) * vp.grid_x), stream, P,
-                                       geom.index_rec, geom.depth_key, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y, by0, by1,
-                                       (const int*)nullptr, (int*)nullptr, g_ablate_fwd);
             }
+            if (!full)
+                hipLaunchKernelGGL(bin_spans_kernel<true>, dim3(nwg), dim3(1024), span_lds_bytes((size_t)lean_band_h * vp.grid_x), stream, P,
+                                   geom.index_rec, geom.depth_key, geom.band_mask, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y,
+                                   lean_band_h, lean_nbands, (const int*)img.num_rendered, (int*)nullptr, g_ablate_fwd);
         }
         STAGE_CHECK("emit entries");
         if (verify) {   // debugging aid: synchronous
@@ -491,14 +501,14 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         const int* key_bits = img.num_rendered + R_SLOTS * R_SLOT_STRIDE + NR_KEY_BITS;
         {
             StageTimer t(stream, MI_STAGE_TILE_SORT);
-            // lists of up to 2048 entries: one wave per tile (bitonic network in registers); longer ones: two classes of the LDS radix
+            // lists of up to 4096 entries: one wave per tile (bitonic network in registers, three length classes); longer ones: two classes of the LDS radix
             // sort (1024 threads + 112 KB, 1024 threads + 144 KB / HBM ping-pong), launched only if some tile needs them.  The longest
             // list was copied to the host right after the range scan, which finished before the emit pass above even started: this
             // wait does not stall the queue.
 #define LAUNCH_TILE_SORT(LO, CAP, FB, NT)                                                                                 \
     hipLaunchKernelGGL((tile_sort_kernel<LO, CAP, FB, NT>), dim3(ntiles), dim3(NT), 0, stream, (uint32_t)ntiles, img.ranges,  \
                        bin.entries, bin.scratch, key_bits, bin.blend_list)
-            hipLaunchKernelGGL(tile_sort_wave_kernel<false>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges,
+            hipLaunchKernelGGL(tile_sort_wave_kernel<0>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges,
                                (const uint2*)bin.entries, bin.blend_list);
             HIP_TRY(hipEventSynchronize(g_host_sync.ev2));
             img.longest_run = longest_of(g_host_sync.pinned + R_SLOTS * R_SLOT_STRIDE + NR_RUN_BOUNDS, (uint32_t)ntiles);
@@ -508,7 +518,10 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
                 return fail(MI_RAST_ERR_HIP, "internal error: tile counts do not add up to num_rendered");
             const int max_tile_count = g_host_sync.pinned[R_SLOTS * R_SLOT_STRIDE + NR_LONGEST];
             if (max_tile_count > 1024)
-                hipLaunchKernelGGL(tile_sort_wave_kernel<true>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges,
+                hipLaunchKernelGGL(tile_sort_wave_kernel<1>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges,
+                                   (const uint2*)bin.entries, bin.blend_list);
+            if (max_tile_count > 2048)
+                hipLaunchKernelGGL(tile_sort_wave_kernel<2>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, (uint32_t)ntiles, img.ranges,
                                    (const uint2*)bin.entries, bin.blend_list);
             if (max_tile_count > TILE_SORT_WAVE_MAX) LAUNCH_TILE_SORT(TILE_SORT_WAVE_MAX, 6144, false, 1024);
             if (max_tile_count > 6144) LAUNCH_TILE_SORT(6144, 8192, true, 1024);
@@ -889,6 +902,7 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_DEPTH_KEY] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_INDEX_REC] = c.take(p * sizeof(BlendRec));
     off[MI_GEOM_CULL_COUNTER] = c.take(16);
+    off[MI_GEOM_BAND_MASK] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_BWD_PACK] = c.take(bwd_pack_bytes((int)p));  // + the backward's work-queue counters, one set per channel block
     return c.off;
 }
