@@ -258,7 +258,7 @@ uint32_t mi_rast_get_higher_msb(uint32_t n);
  * fields listed, and returns the total size in bytes. */
 enum { MI_GEOM_DEPTHS = 0, MI_GEOM_MEANS2D, MI_GEOM_CONIC_OPACITY, MI_GEOM_COV3D, MI_GEOM_RGB,
        MI_GEOM_CLAMPED, MI_GEOM_TILES_TOUCHED, MI_GEOM_DEPTH_KEY, MI_GEOM_INDEX_REC,
-       MI_GEOM_CULL_COUNTER, MI_GEOM_BAND_MASK, MI_GEOM_BWD_PACK, MI_GEOM_NFIELDS };
+       MI_GEOM_CULL_COUNTER, MI_GEOM_BAND_BITS, MI_GEOM_BWD_PACK, MI_GEOM_NFIELDS };
 enum { MI_IMG_FINAL_T = 0, MI_IMG_N_CONTRIB, MI_IMG_RANGES, MI_IMG_TILE_CONSUMED, MI_IMG_TILE_COUNT,
        MI_IMG_TILE_CURSOR, MI_IMG_NUM_RENDERED, MI_IMG_TILE_NSURV, MI_IMG_NFIELDS };
 /* MI_BIN_BLEND_LIST: u32[R], per tile at ranges[tile].x in depth order: Gaussian id | quadrant mask << 28 -- all the blend kernels

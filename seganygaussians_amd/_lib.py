@@ -10,7 +10,7 @@ from .build import LIB_PATH
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 MI_GEOM_FIELDS = ["depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped", "tiles_touched",
-                  "depth_key", "index_rec", "cull_counter", "band_mask", "bwd_pack"]
+                  "depth_key", "index_rec", "cull_counter", "band_bits", "bwd_pack"]
 MI_IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_consumed", "tile_count", "tile_cursor", "num_rendered", "tile_nsurv"]
 MI_BIN_FIELDS = ["entries", "scratch", "blend_list"]
 MI_RAST_FULL_LISTS, MI_RAST_F32_BLEND, MI_RAST_NO_CULL, MI_RAST_FAST_EXP, MI_RAST_VERIFY_LISTS, MI_RAST_TILE_FWD = 1, 2, 4, 8, 16, 32   # `flags` of mi_rast_forward (include/mi_rast.h)

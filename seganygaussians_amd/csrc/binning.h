@@ -133,6 +133,8 @@ constexpr int ID_BITS = 28;            // list entry = Gaussian id | quadrant ma
 constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
 constexpr int BIN_MAX_WG = 256;        // workgroups of the count / emit passes (slices of the Gaussians): one per CU, all resident at once
 constexpr int BIN_THREADS = 1024;
+constexpr int BIN_LEAN_WG = 256;       // workgroups of the LEAN count / emit passes (dealt to the bands by load, binning.h: band_plan)
+constexpr int BIN_LEAN_WG_MAX = 1024;  // (upper bound of the profiling build's MI_RAST_LEAN_NWG knob)
 constexpr int BIN_MAX_TILES = 22 * 1024 - 64;  // per launch of the count / emit passes: one LDS counter per tile + 61 KB of hand-off
                                                // arrays must fit in 160 KB; larger images are walked in bands of tile rows
 constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 128;  // tile_ranges_kernel scans all tile totals in one workgroup's LDS
@@ -142,9 +144,9 @@ constexpr int BIN_MAX_TILES_TOTAL = 40 * 1024 - 128;  // tile_ranges_kernel scan
 // cover that band's tiles only, and -- the point -- the entries it stores go to a few hundred tile segments instead of all of them:
 // ~22 consecutive entries per (workgroup, tile) on cfg3 instead of 1.4, which the L2 of the workgroup's XCD merges into whole lines
 // (tools/write_combine_probe.hip: the same 2.93 M eight-byte stores take 16.5 us banded, 30 us with every workgroup storing into every
-// tile's segment; WRITE_SIZE of rounds 2-5 was 64 bytes per entry).  The preprocess pass leaves one bit per band in band_mask[g] and
-// the number of Gaussians per band (r_slots); a band gets workgroups in proportion to that number (band_plan), every workgroup an
-// equal share of the Gaussian INDEX range, of which it picks the Gaussians with its band's bit.
+// tile's segment; WRITE_SIZE of rounds 2-5 was 64 bytes per entry).  The preprocess pass leaves, per band, one bit per Gaussian (band_bits[band][index chunk]:
+// a wave's ballot) and the number of Gaussians per band (r_slots); a band gets workgroups in proportion to that number (band_plan), every workgroup an
+// equal share of the Gaussian INDEX range, of which it picks the Gaussians with its band's bit (64 Gaussians per word).
 __host__ __device__ inline bool band_geometry(uint32_t gx, uint32_t gy, uint32_t max_head_words, uint32_t& band_h, uint32_t& nbands)
 {
     band_h = (gy + 15u) / 16u;
@@ -187,11 +189,7 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
                                                            uint32_t* __restrict__ zero_a = nullptr, uint32_t* __restrict__ zero_b = nullptr,
                                                            uint32_t* __restrict__ run_bounds = nullptr /* [9]: the blend kernels' XCD runs
                                                                (common.h): equal tile counts, or equal MODELLED work when run_cap > 0 */,
-                                                           uint32_t run_cap = 0, uint32_t run_fix = 0,
-                                                           uint32_t* __restrict__ band_partial = nullptr /* lean lists: [workgroup][tile of its
-                                                               band] counts of the banded count pass; the scan over a tile's workgroups happens HERE
-                                                               (in place: exclusive prefix), tile_total is not read */,
-                                                           uint32_t gx = 0, uint32_t band_h = 0, uint32_t nbands = 0, uint32_t nwg_plan = 0)
+                                                           uint32_t run_cap = 0, uint32_t run_fix = 0)
 {
     // The totals are staged in LDS (coalesced), thread t scans the contiguous items [t*per, (t+1)*per) in place,
     // one workgroup scan joins the pieces, and the ranges leave coalesced again.
@@ -211,11 +209,8 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
     const bool weighted = run_bounds != nullptr && run_cap > 0u && ntiles_all <= BIN_MAX_TILES_TOTAL;   // (one segment)
     __shared__ uint32_t s_maxcount;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ uint32_t s_plan[MAX_BANDS + 1];
-    if (band_partial != nullptr && wave == 0) band_plan(r_slots, nbands, nwg_plan, s_plan, lane);
     if (tid < 9) s_bound[tid] = xcd_run_start((uint32_t)tid, (uint32_t)ntiles_all);   // equal tile counts unless the model says otherwise
     if (tid == 0) s_maxcount = 0;
-    if (band_partial != nullptr) __syncthreads();
     if (wave == 15 && r_slots != nullptr) {   // (a wave that has the least to do below)
         uint32_t inv_min = (uint32_t)r_slots[(lane % R_SLOTS) * R_SLOT_STRIDE + 1];
         uint32_t mx = (uint32_t)r_slots[(lane % R_SLOTS) * R_SLOT_STRIDE + 2];
@@ -231,23 +226,7 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles_all, const
     uint32_t carry = 0;   // entries in front of the segment (the same in every thread)
     for (int seg0 = 0; seg0 < ntiles_all; seg0 += BIN_MAX_TILES_TOTAL) {
         const int ntiles = min(BIN_MAX_TILES_TOTAL, ntiles_all - seg0);
-        if (band_partial != nullptr) {
-            // a tile's entries come from the workgroups of its band: total = their sum, and every workgroup's share is replaced by
-            // what lies in front of it inside the tile's segment (0.6 MB in all on a 1080p view)
-            const uint32_t btm = band_h * gx;
-            for (int i = tid; i < ntiles; i += 1024) {
-                const uint32_t t = (uint32_t)(seg0 + i), b = (t / gx) / band_h, tl = t - b * btm;
-                uint32_t run = 0;
-                for (uint32_t w = s_plan[b]; w < s_plan[b + 1]; w++) {
-                    const uint32_t c = band_partial[(size_t)w * btm + tl];
-                    band_partial[(size_t)w * btm + tl] = run;
-                    run += c;
-                }
-                s_val[i] = run;
-            }
-        } else {
-            for (int i = tid; i < ntiles; i += 1024) s_val[i] = tile_total[seg0 + i];
-        }
+        for (int i = tid; i < ntiles; i += 1024) s_val[i] = tile_total[seg0 + i];
         __syncthreads();
         const int per = (ntiles + 1023) / 1024;
         const int i0 = min(ntiles, tid * per), i1 = min(ntiles, i0 + per);
@@ -459,7 +438,8 @@ __global__ void __launch_bounds__(1024) run_bounds_from_walks_kernel(int ntiles,
 // blend kernels gather per list entry.
 struct __attribute__((aligned(16))) BlendRec {
     float2 xy;       // pixel-space mean
-    uint32_t id;     // Gaussian index (feature row)
+    uint32_t id;     // index_rec: the DEPTH BITS of the Gaussian (its index is where the record lies; the emit pass gets the sort key with the
+                     // record instead of a second 4-byte gather); a staged list record (list_record): the Gaussian index (feature row)
     uint32_t pm;     // (position in the tile list) << 4 | quadrant mask
     float4 co;       // conic A,B,C + opacity
 };
@@ -472,6 +452,7 @@ __device__ __forceinline__ BlendRec list_record(const uint32_t* __restrict__ lst
 {
     const uint32_t e = lst[i];
     BlendRec r = index_rec[e & ID_MASK];
+    r.id = e & ID_MASK;   // (the stored word holds the depth bits)
     r.pm = ((uint32_t)i << 4) | (e >> ID_BITS);
     return r;
 }
@@ -646,8 +627,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(int P, const Ble
 // on cfg3, ~1 us per phase whatever it computed).  Hand-offs between the lanes of a wave go through wave-private LDS words;
 // LDS operations of one wave execute in program order, the wavefront fences keep the compiler from reordering them.
 // Measured on cfg3: 2.27 M (Gaussian, row) items, 2.93 M entries.
-constexpr int BW_WORDS = 64 * 22;  // LDS words per wave: prefix, rect, depth bits, id, owner scratch, two float4 of span constants + mean, the id queue (5 x 64); emit: span prefix, two bands' columns, span origin
-constexpr int SPAN_MASK_CHUNKS = 4;   // band-mask chunks (64 Gaussians each) a wave takes from its workgroup's counter at a time
+constexpr int BW_WORDS = 64 * 18;  // LDS words per wave: prefix, rect, depth bits, id, owner scratch, two float4 of span constants + mean, the ids of a chunk; emit: span prefix, two bands' columns, span origin
 __host__ __device__ constexpr size_t span_lds_bytes(size_t head_words) { return (((head_words + 3) & ~(size_t)3) + 4 + 16 * BW_WORDS) * sizeof(uint32_t); }
 constexpr uint32_t SPAN_MAX_HEAD_WORDS = 40 * 1024 - 16 * BW_WORDS - 64;   // counters / cursors of one band: what is left of 160 KB
 
@@ -684,8 +664,8 @@ __device__ __forceinline__ uint32_t wave_owner(uint32_t* scratch /* [64] wave-pr
 
 template <bool EMIT>
 __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* __restrict__ index_rec,
-                                                         const uint32_t* __restrict__ depth_key, const uint32_t* __restrict__ band_mask,
-                                                         uint32_t* __restrict__ partial, const uint2* __restrict__ ranges,
+                                                         const uint32_t* __restrict__ depth_key, const unsigned long long* __restrict__ band_bits,
+                                                         uint32_t* __restrict__ partial, uint32_t* __restrict__ tile_total, const uint2* __restrict__ ranges,
                                                          uint2* __restrict__ entries, uint32_t gx, uint32_t gy_all,
                                                          uint32_t band_h, uint32_t nbands, const int* __restrict__ r_slots,
                                                          int* __restrict__ host_r, int ablate)
@@ -726,7 +706,7 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
     uint32_t* w_q1 = wb + 896;         //   lower band's columns lo | hi << 11
     uint32_t* w_sx = wb + 960;         //   first tile column | tile row << 10
     uint32_t* w_id = wb + 1024;        // Gaussian id of the lane's record
-    uint32_t* w_queue = wb + 1088;     // [192]: ids of this band's Gaussians, in index order, waiting for a full chunk
+    uint32_t* w_queue = wb + 1088;     // [64]: ids of the chunk being put together
     uint32_t* my_partial = partial + (size_t)blockIdx.x * (band_h * gx);   // [workgroup][tile of its band]
     if (EMIT) {
         for (int t = tid; t < ntiles; t += 1024) s_cnt[t] = ranges[tile0 + t].x + my_partial[t];
@@ -735,70 +715,69 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
     }
     if (tid == 0) s_next[0] = 0u;
     __syncthreads();
-    // This workgroup's share of the Gaussians: mask chunks (64 consecutive indices) [c0, c1) of the view's, an equal part of the
-    // index range for each of the band's workgroups.  A wave takes SPAN_MASK_CHUNKS of them at a time from the LDS counter, keeps
-    // the ids whose band bit is set in a wave-private queue, and walks a chunk of 64 queued Gaussians whenever one is full.
+    // This workgroup's share of the Gaussians: index chunks (64 consecutive indices) [mc0, mc1) of the view's, an equal part of the
+    // index range for each of the band's workgroups.
     const uint32_t nchunks_all = ((uint32_t)P + 63u) / 64u;
     const uint32_t mc0 = (uint32_t)(((uint64_t)sub * nchunks_all) / nsub), mc1 = (uint32_t)(((uint64_t)(sub + 1u) * nchunks_all) / nsub);
-    uint32_t qn = 0;          // ids in the queue (wave-uniform)
-    // group of mask chunks requested ahead: its first chunk (>= mc1: none left) and the lanes' mask words, in flight while the
-    // previous group is sifted and the previous chunk of Gaussians is walked (unconditional loads, clamped: a conditionally assigned
-    // load result is waited for on the spot; validity is applied where the words are used)
-    uint32_t g_next;
-    uint32_t m_next[SPAN_MASK_CHUNKS];
-    auto request_masks = [&]() __attribute__((always_inline)) {
-        uint32_t g = 0;
-        if (lane == 0) g = atomicAdd(s_next, (uint32_t)SPAN_MASK_CHUNKS);
-        g_next = mc0 + (uint32_t)__builtin_amdgcn_readfirstlane(g);
-#pragma unroll
-        for (int k = 0; k < SPAN_MASK_CHUNKS; k++)
-            m_next[k] = band_mask[min((g_next + (uint32_t)k) * 64u + (uint32_t)lane, (uint32_t)P - 1u)];
+    // The band's Gaussians come as bit words: band_bits[band][c] = which of the 64 Gaussians of index chunk c reach this band
+    // (geometry.h).  A wave takes UNITS of 32 words (2048 Gaussians) from the workgroup's LDS counter, one unit requested ahead; the
+    // set bits of a unit are ranked (popcount + DPP scan over the lanes' words), and a chunk of <= 64 Gaussians is the next 64 ranks:
+    // every lane whose word holds some of them walks its set bits and leaves the ids in the wave's queue.
+    constexpr uint32_t UNIT = 32;
+    const unsigned long long* my_bits = band_bits + (size_t)band * nchunks_all;
+    uint32_t g_unit = 0, g_next;                    // first index chunk of the unit being sifted / of the one requested ahead
+    unsigned long long word = 0ull, nword;          // lane L < 32: the word of chunk g_unit + L
+    uint32_t cnt = 0, incl = 0, total = 0, r0 = 0;  // the lane's set bits, their inclusive prefix over the lanes, the unit's sum, ranks taken so far
+    auto request_unit = [&]() __attribute__((always_inline)) {
+        uint32_t u = 0;
+        if (lane == 0) u = atomicAdd(s_next, 1u);
+        g_next = mc0 + UNIT * (uint32_t)__builtin_amdgcn_readfirstlane(u);
+        nword = my_bits[min(g_next + (uint32_t)lane, nchunks_all - 1u)];   // (unconditional, clamped; validity is applied in next_unit)
     };
-    // next chunk of <= 64 queued Gaussians -> id (0xFFFFFFFF: lane without one); false: this workgroup's share is exhausted
+    auto next_unit = [&]() __attribute__((always_inline)) {
+        g_unit = g_next;
+        word = ((uint32_t)lane < UNIT && g_unit + (uint32_t)lane < mc1) ? nword : 0ull;
+        request_unit();
+        cnt = (uint32_t)__builtin_popcountll(word);
+        incl = wave_inclusive_scan_dpp(cnt);
+        total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        r0 = 0;
+    };
+    // next chunk of <= 64 Gaussians of this band -> id (0xFFFFFFFF: lane without one); false: this workgroup's share is exhausted
     auto take_chunk = [&](uint32_t& id) __attribute__((always_inline)) -> bool {
-        while (qn < 64u && g_next < mc1) {
-            const uint32_t g = g_next;
-            uint32_t m[SPAN_MASK_CHUNKS];
-#pragma unroll
-            for (int k = 0; k < SPAN_MASK_CHUNKS; k++) m[k] = m_next[k];
-            request_masks();
-#pragma unroll
-            for (int k = 0; k < SPAN_MASK_CHUNKS; k++) {
-                const uint32_t i = (g + (uint32_t)k) * 64u + (uint32_t)lane;
-                const bool mine = g + (uint32_t)k < mc1 && i < (uint32_t)P && (m[k] & band_bit) != 0u;
-                const uint64_t bal = ballot64(mine);
-                if (mine) w_queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = i;
-                qn += (uint32_t)__builtin_popcountll(bal);   // (<= 63 + 4 x 64: the queue holds 5 x 64 words)
+        uint32_t qn = 0;
+        while (qn < 64u) {
+            if (r0 == total) {
+                if (g_next >= mc1) break;
+                next_unit();
+                continue;
             }
+            const uint32_t t = min(64u - qn, total - r0);
+            uint32_t rk = incl - cnt;   // rank of this lane's first set bit
+            if (incl > r0 && rk < r0 + t) {
+                for (unsigned long long w = word; w != 0ull; w &= w - 1ull, rk++)
+                    if (rk >= r0 && rk < r0 + t) w_queue[qn + rk - r0] = (g_unit + (uint32_t)lane) * 64u + (uint32_t)__builtin_ctzll(w);
+            }
+            r0 += t;
+            qn += t;
         }
         if (qn == 0u) return false;
         wave_lds_fence();
-        const uint32_t take = min(qn, 64u);
-        id = (uint32_t)lane < take ? w_queue[lane] : 0xFFFFFFFFu;
-        uint32_t rest[4];   // the rest of the queue moves to its front
-#pragma unroll
-        for (int k = 0; k < 4; k++) rest[k] = w_queue[64 + 64 * k + lane];
+        id = (uint32_t)lane < qn ? w_queue[lane] : 0xFFFFFFFFu;
         wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < 4; k++) w_queue[64 * k + lane] = rest[k];
-        wave_lds_fence();
-        qn -= take;
         return true;
     };
-    request_masks();
+    request_unit();
     uint32_t nid = 0xFFFFFFFFu;
     bool have = take_chunk(nid);
     BlendRec nrec = index_rec[nid == 0xFFFFFFFFu ? 0u : nid];
-    uint32_t nkey = depth_key[nid == 0xFFFFFFFFu ? 0u : nid];
     while (have) {
         const uint32_t id = nid;
         const BlendRec rec = nrec;
-        const uint32_t key = nkey;
         // the next chunk's ids, and its records requested before this chunk's items are walked
         nid = 0xFFFFFFFFu;
         have = take_chunk(nid);
         nrec = index_rec[nid == 0xFFFFFFFFu ? 0u : nid];
-        nkey = depth_key[nid == 0xFFFFFFFFu ? 0u : nid];
         uint32_t h = 0;
         if (id != 0xFFFFFFFFu) {   // visible (its band bit was set): radius > 0, record written (geometry.h)
             const int rad = (int)rec.pm;
@@ -815,7 +794,7 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
                 w_c1[lane] = make_float4(pre.cull ? pre.ey : -1.0f, pre.ystar, rec.xy.x, rec.xy.y);
                 w_rect[lane] = rmin.x | (rmax.x << 10) | (rmin.y << 21);
                 if (EMIT) {
-                    w_key[lane] = key;
+                    w_key[lane] = rec.id;   // depth bits (BlendRec)
                     w_id[lane] = id;
                 }
             }
@@ -909,7 +888,11 @@ __global__ void __launch_bounds__(1024) bin_spans_kernel(int P, const BlendRec* 
                 const int x = x0 + lane;
                 int v = x < (int)gx ? s_grid[y * stride + x] : 0;
                 v = (int)wave_inclusive_scan_dpp((uint32_t)v) + carry;   // (two's complement: the signed differences add up like unsigned words)
-                if (x < (int)gx) my_partial[y * (int)gx + x] = (uint32_t)v;
+                // this workgroup's entries of the tile take the next v slots of the tile's segment: one returning atomic per
+                // (workgroup, non-empty tile) on the tile's total -- ~130 K of them per cfg3 view, ~18 per address, in place of a
+                // partial[slice][tile] table and its scan (the order of the workgroups inside a segment is whatever the atomics
+                // make it: the per-tile sort does not care)
+                if (x < (int)gx) my_partial[y * (int)gx + x] = v != 0 ? atomicAdd(&tile_total[tile0 + y * (int)gx + x], (uint32_t)v) : 0u;
                 carry = __builtin_amdgcn_readlane(v, 63);
             }
         }
@@ -1222,7 +1205,7 @@ __device__ __forceinline__ void tile_sort_in_wave(const uint2* __restrict__ seg,
     double a[EPL];
 #pragma unroll
     for (int r = 0; r < EPL; r++) {
-        const int e = lane * EPL + r;
+        const int e = r * 64 + lane;   // (any order will do going IN: coalesced loads; the sorted sequence is indexed lane * EPL + r)
         uint64_t w = 0x7FEFFFFFFFFFFFFFull;   // padding: the largest finite binary64, behind every entry
         if (e < n) {
             const uint2 p = seg[e];

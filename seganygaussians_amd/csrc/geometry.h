@@ -121,12 +121,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int* __restrict__ radii, float2* __restrict__ points_xy_image, float* __restrict__ depths,
     float* __restrict__ cov3Ds, float* __restrict__ rgb, float4* __restrict__ conic_opacity,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, BlendRec* __restrict__ index_rec,
-    int* __restrict__ r_slots, int prefiltered, int* __restrict__ culled_prefiltered, uint32_t* __restrict__ band_mask,
-    uint32_t band_h, uint32_t nbands)
+    int* __restrict__ r_slots, int prefiltered, int* __restrict__ culled_prefiltered, unsigned long long* __restrict__ band_bits,
+    uint32_t band_h, uint32_t nbands, uint32_t* __restrict__ tile_total, uint32_t ntiles)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t s_band[MAX_BANDS];   // Gaussians of this workgroup per band of tile rows (binning.h: lean count / emit passes)
     if (threadIdx.x < MAX_BANDS) s_band[threadIdx.x] = 0u;
+    if ((uint32_t)idx < ntiles) tile_total[idx] = 0u;   // per-tile entry counts: the count pass adds to them (binning.h); P < tiles: host memset
     // SH colours (forward.cu:23-74 reads 3 M floats per Gaussian, 192 bytes at degree 3): a thread walking its own row makes
     // every load instruction of the wave touch 64 rows 192 bytes apart.  The workgroup's rows are one contiguous block of
     // memory: staged into LDS with coalesced 16-byte loads (culled Gaussians included: 25 % more bytes, all of them streamed),
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             // everything the binning stages need of this Gaussian in one 32-byte record (depth_sort.h gathers it once)
             BlendRec rec;
             rec.xy = point_image;
-            rec.id = (uint32_t)idx;
+            rec.id = my_key;   // the depth bits ride in the record (binning.h: BlendRec)
             rec.pm = (uint32_t)my_radii;
             rec.co = make_float4(conic.x, conic.y, conic.z, opacities[idx]);
             index_rec[idx] = rec;
@@ -226,7 +227,17 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         radii[idx] = my_radii;
         tiles_touched[idx] = my_tiles;
         depth_key[idx] = my_key;
-        band_mask[idx] = my_bands;
+    }
+    // band_bits[b][w]: which of the 64 Gaussians of wave w (= 64-index chunk w of the view) reach band b -- one ballot per band, lane b
+    // stores band b's word: the count / emit workgroups of a band sift 64 Gaussians per word instead of reading a mask per Gaussian
+    {
+        unsigned long long mine = 0ull;
+        for (uint32_t b = 0; b < nbands; b++) {
+            const unsigned long long bal = ballot64(((my_bands >> b) & 1u) != 0u);
+            if ((uint32_t)(threadIdx.x & 63) == b) mine = bal;
+        }
+        const uint32_t chunk = (uint32_t)idx >> 6, nchunks = ((uint32_t)P + 63u) >> 6;
+        if ((uint32_t)(threadIdx.x & 63) < nbands && chunk < nchunks) band_bits[(size_t)(threadIdx.x & 63) * nchunks + chunk] = mine;
     }
     __syncthreads();   // (s_band zeroed; the SH staging barrier above is conditional)
     for (uint32_t m = my_bands; m != 0u; m &= m - 1u) atomicAdd(&s_band[__builtin_ctz(m)], 1u);

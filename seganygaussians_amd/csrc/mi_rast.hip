@@ -191,7 +191,7 @@ struct GeomPtrs {
     uint32_t* depth_key;
     BlendRec* index_rec;  // [P] {mean, id, radius, conic + opacity} in index order (written by the preprocess pass for visible Gaussians)
     int* cull_counter;    // one word: Gaussians culled although `prefiltered` was set
-    uint32_t* band_mask;  // [P] one bit per band of tile rows the Gaussian's rect reaches (binning.h: lean count / emit passes)
+    unsigned long long* band_bits;  // [MAX_BANDS][ceil(P / 64)]: per band of tile rows, one bit per Gaussian whose rect reaches it (binning.h)
     float* bwd_pack;  // [P,8] packed per-Gaussian field gradients (backward scratch)
 };
 struct ImgPtrs {
@@ -229,7 +229,7 @@ GeomPtrs geom_from(char* base, int P)
     g.depth_key = (uint32_t*)(base + off[MI_GEOM_DEPTH_KEY]);
     g.index_rec = (BlendRec*)(base + off[MI_GEOM_INDEX_REC]);
     g.cull_counter = (int*)(base + off[MI_GEOM_CULL_COUNTER]);
-    g.band_mask = (uint32_t*)(base + off[MI_GEOM_BAND_MASK]);
+    g.band_bits = (unsigned long long*)(base + off[MI_GEOM_BAND_BITS]);
     g.bwd_pack = (float*)(base + off[MI_GEOM_BWD_PACK]);
     return g;
 }
@@ -367,13 +367,16 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     {
         StageTimer t(stream, MI_STAGE_PREPROCESS);
         HIP_TRY(hipMemsetAsync(img.num_rendered, 0, R_SLOTS * R_SLOT_STRIDE * sizeof(int), stream));
+        // (the per-tile entry totals are zeroed by the preprocess kernel's first threads; fewer Gaussians than tiles: by a fill)
+        if (P < ntiles) HIP_TRY(hipMemsetAsync(img.tile_cursor, 0, (size_t)ntiles * sizeof(uint32_t), stream));
         // SH colours: the workgroup's coefficient rows are staged in LDS (geometry.h), 256 rows of 3 M + 4 floats
         const size_t sh_lds = colors_given ? 0 : (size_t)256 * (3 * (size_t)M + 4) * sizeof(float);
         if (sh_lds > 64 * 1024) return fail(MI_RAST_ERR_INVALID, "too many SH coefficients per Gaussian (at most 16: degree 3)");
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), sh_lds, stream, P, D, M, means3D, scales,
                            rotations, opacities, shs, geom.clamped, cov3D_precomp, colors_given, vp, radii,
                            geom.means2D, geom.depths, geom.cov3D, geom.rgb, geom.conic_opacity, geom.tiles_touched,
-                           geom.depth_key, geom.index_rec, img.num_rendered, prefiltered, cull_counter, geom.band_mask, lean_band_h, lean_nbands);
+                           geom.depth_key, geom.index_rec, img.num_rendered, prefiltered, cull_counter, geom.band_bits, lean_band_h, lean_nbands,
+                           img.tile_cursor, (uint32_t)ntiles);
     }
     STAGE_CHECK("preprocess");
     if (prefiltered) {
@@ -409,7 +412,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
     const bool full = debug != 0 || nocull || (flags & MI_RAST_FULL_LISTS) != 0;
     // full lists: <= 256 workgroups of 1024 threads, each a slice of the Gaussians (64-index chunks dealt round robin); lean lists:
     // workgroups dealt to the bands in proportion to the bands' Gaussian counts (binning.h: band_plan), at least one per band
-    int nwg = full ? bin_workgroups(P) : std::min(BIN_MAX_WG, (int)lean_nbands + (P + 1023) / 1024);
+    int nwg = full ? bin_workgroups(P) : std::min(knob("MI_RAST_LEAN_NWG", BIN_LEAN_WG), (int)lean_nbands + (P + 1023) / 1024);
 #ifdef MI_RAST_PROFILING
     if (ablate_env("MI_RAST_NWG") > 0) nwg = std::min(nwg, ablate_env("MI_RAST_NWG"));
 #endif
@@ -428,13 +431,13 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         }
         if (!full)
             hipLaunchKernelGGL(bin_spans_kernel<false>, dim3(nwg), dim3(1024), span_lds_bytes((size_t)lean_band_h * count_grid_stride(vp.grid_x)),
-                               stream, P, geom.index_rec, geom.depth_key, geom.band_mask, img.tile_count, (const uint2*)nullptr, (uint2*)nullptr,
+                               stream, P, geom.index_rec, geom.depth_key, geom.band_bits, img.tile_count, img.tile_cursor, (const uint2*)nullptr, (uint2*)nullptr,
                                vp.grid_x, vp.grid_y, lean_band_h, lean_nbands, (const int*)img.num_rendered, g_host_sync.pinned_dev, g_ablate_fwd);
         HIP_TRY(hipEventRecord(g_host_sync.ev, stream));
         // (one launch for both scans -- every workgroup scans its tiles over the slices, the last one to finish scans the totals
         // behind a device-scope counter and agent-scope fences -- was built and measured in round 4: tile scan 0.058 -> 0.060 ms
         // on cfg3; the fences and the serial tail inside the kernel cost more than the launch they save)
-        // full lists: scan over (tile, slice) here; lean lists: the range scan below sums a tile's workgroups itself (0.6 MB)
+        // full lists: scan over (tile, slice); lean lists: the count pass left the tile totals and every workgroup's offset itself
         if (full)
             hipLaunchKernelGGL(scan_partials_kernel, dim3((ntiles + 63) / 64), dim3(1024), 0, stream, ntiles, nwg,
                                img.tile_count, img.tile_cursor);
@@ -443,8 +446,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024),
                            ((size_t)std::min(ntiles, BIN_MAX_TILES_TOTAL) + 1) * sizeof(uint32_t), stream, ntiles, img.tile_cursor,
                            img.ranges, img.num_rendered + R_SLOTS * R_SLOT_STRIDE, (const int*)img.num_rendered,
-                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds, run_cap, run_fix,
-                           full ? (uint32_t*)nullptr : img.tile_count, vp.grid_x, lean_band_h, lean_nbands, (uint32_t)nwg);
+                           g_host_sync.pinned_dev + R_SLOTS * R_SLOT_STRIDE, img.tile_consumed, img.tile_nsurv, img.run_bounds, run_cap, run_fix);
     }
     STAGE_CHECK("tile scan");
     HIP_TRY(hipEventRecord(g_host_sync.ev2, stream));
@@ -483,7 +485,7 @@ int geometry_and_binning(mi_rast_resize_fn geometry_buffer, void* geometry_user,
             }
             if (!full)
                 hipLaunchKernelGGL(bin_spans_kernel<true>, dim3(nwg), dim3(1024), span_lds_bytes((size_t)lean_band_h * vp.grid_x), stream, P,
-                                   geom.index_rec, geom.depth_key, geom.band_mask, img.tile_count, img.ranges, bin.entries, vp.grid_x, vp.grid_y,
+                                   geom.index_rec, geom.depth_key, geom.band_bits, img.tile_count, img.tile_cursor, img.ranges, bin.entries, vp.grid_x, vp.grid_y,
                                    lean_band_h, lean_nbands, (const int*)img.num_rendered, (int*)nullptr, g_ablate_fwd);
         }
         STAGE_CHECK("emit entries");
@@ -902,7 +904,7 @@ size_t mi_rast_geometry_layout(int P, size_t* off)
     off[MI_GEOM_DEPTH_KEY] = c.take(p * sizeof(uint32_t));
     off[MI_GEOM_INDEX_REC] = c.take(p * sizeof(BlendRec));
     off[MI_GEOM_CULL_COUNTER] = c.take(16);
-    off[MI_GEOM_BAND_MASK] = c.take(p * sizeof(uint32_t));
+    off[MI_GEOM_BAND_BITS] = c.take((size_t)MAX_BANDS * ((p + 63) / 64) * sizeof(unsigned long long));
     off[MI_GEOM_BWD_PACK] = c.take(bwd_pack_bytes((int)p));  // + the backward's work-queue counters, one set per channel block
     return c.off;
 }
@@ -916,7 +918,7 @@ size_t mi_rast_image_layout(int width, int height, size_t* off)
     off[MI_IMG_RANGES] = c.take((tiles ? tiles : 1) * sizeof(uint2));
     off[MI_IMG_TILE_CONSUMED] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     // tile_count holds partial[slice][tile] of the count / emit passes (binning.h); tile_cursor the tile totals
-    constexpr int max_slices = BIN_MAX_WG;
+    constexpr int max_slices = BIN_MAX_WG;   // (the lean passes' [workgroup][tile of its band] table is far smaller: BIN_LEAN_WG_MAX x a band's tiles)
     off[MI_IMG_TILE_COUNT] = c.take((size_t)max_slices * (tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_TILE_CURSOR] = c.take((tiles ? tiles : 1) * sizeof(uint32_t));
     off[MI_IMG_NUM_RENDERED] = c.take((R_SLOTS * R_SLOT_STRIDE + 16) * sizeof(int));  // R partial sums, then {R, longest list}, then the nine run boundaries

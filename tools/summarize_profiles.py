@@ -38,10 +38,12 @@ def short(n):
 STAGE_BY_BASE = {"blend_bwd_wave_kernel": "blend_bwd", "blend_bwd_kernel": "blend_bwd",
                  "blend_fwd_kernel": "blend_fwd", "blend_fwd_x3_kernel": "blend_fwd", "blend_fwd_wave_kernel": "blend_fwd", "blend_fwd_wave_rgb_kernel": "blend_fwd",
                  "run_bounds_from_walks_kernel": "blend_fwd",
-                 "preprocess_fwd_kernel": "preprocess", "bin_count_kernel": "tile_scan", "bin_ranks_kernel": "emit", "verify_entries_kernel": "emit",
-                 "tile_sort_kernel": "tile_sort", "scan_partials_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
+                 "preprocess_fwd_kernel": "preprocess",
+                 "tile_sort_kernel": "tile_sort", "tile_sort_wave_kernel": "tile_sort", "reuse_image_state_kernel": "tile_scan", "tile_ranges_kernel": "tile_scan",
                  "geometry_bwd_kernel": "geom_bwd", "unpack_mask_kernel": "geom_bwd"}
 STAGE_BY_FIRST_ARG = {"bin_spans_kernel": {"true": "emit", "false": "tile_scan"}}
+# kernels of the FULL-list mode (parity tests; bench.py runs them once, in its counter step): listed in the tables, part of no stage
+PARITY_ONLY = ("bin_count_kernel", "bin_ranks_kernel", "scan_partials_kernel", "verify_entries_kernel")
 
 
 def base_and_args(name):
@@ -76,7 +78,7 @@ tot = sum(v[1] for v in agg.values())
 unmapped = {}
 for r in rows:
     base, args, ours = base_and_args(r["Name"])
-    if ours and stage_of(r["Name"]) is None and not base.startswith("knn") and not base.startswith("contrastive"):
+    if ours and stage_of(r["Name"]) is None and not base.startswith(("knn", "contrastive", "fingerprint")) and base not in PARITY_ONLY:
         unmapped[base] = unmapped.get(base, 0) + int(r["TotalDurationNs"])
 bad = {k: v for k, v in unmapped.items() if v > 0.01 * tot}
 if bad:
