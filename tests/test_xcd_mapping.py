@@ -144,3 +144,106 @@ def test_forward_runs_cover_every_quadrant_once():
             grid = 32 * fwd_longest(n, m)
             got = sorted(4 * it[0] + it[1] for it in (fwd_item(wg, n, m) for wg in range(grid)) if it is not None)
             assert got == list(range(4 * n)), (n, m)
+
+
+def fwd_item_runs(wg, b):
+    """blend_fwd_wave.h: fwd_wave_item with m == 0 -- the PRODUCT path: one run per XCD, boundaries from the range scan."""
+    x, jj = wg & 7, wg >> 3
+    tl, quad = jj >> 2, jj & 3
+    start, length = b[x], b[x + 1] - b[x]
+    return (start + tl, quad) if tl < length else None
+
+
+def longest_of(b, n):
+    """mi_rast.hip: longest_of -- what sizes the forward's grid."""
+    longest = max(max(b1 - b0, 0) for b0, b1 in zip(b, b[1:]))
+    return min(max(longest, (n + 7) >> 3), max_run(n))
+
+
+def piece_search_bounds(counts, cap, fix):
+    """binning.h: tile_ranges_kernel with run_cap > 0, as the kernel does it: 1024 threads own contiguous pieces of `per` tiles, a
+    boundary k lies in the ONE piece whose weight prefix brackets k W / 8, and that piece's thread walks its tiles."""
+    n = len(counts)
+    w = np.minimum(np.asarray(counts, np.int64), cap) + fix
+    per = (n + 1023) // 1024
+    starts = [min(n, t * per) for t in range(1024)]
+    ends = [min(n, s + per) for s in starts]
+    piece_w = [int(w[s:e].sum()) for s, e in zip(starts, ends)]
+    incl = np.cumsum(piece_w)
+    total = int(incl[-1])
+    b = [run_start(x, n) for x in range(9)]
+    for t in range(1024):
+        w_lo, w_hi = 8 * (int(incl[t]) - piece_w[t]), 8 * int(incl[t])
+        for k in range(1, 8):
+            want = k * total
+            if w_lo < want <= w_hi:
+                acc, i = w_lo, starts[t]
+                while i < ends[t]:
+                    acc += 8 * int(w[i])
+                    if acc >= want:
+                        break
+                    i += 1
+                b[k] = min(i + 1, ends[t])
+    return clamp_runs(b, n)
+
+
+def test_product_forward_mapping_and_piece_search():
+    """The paths the product takes: m == 0 with the range scan's boundaries, and the piece-granular boundary search of
+    tile_ranges_kernel against the plain searchsorted restatement (bounds_from_model)."""
+    rng = np.random.default_rng(2)
+    for n in (1, 7, 8, 255, 6700, 8160, 34680):
+        for law in range(3):
+            counts = (rng.integers(0, 50, n) if law == 0 else
+                      np.where(np.arange(n) < n // 3, rng.integers(800, 3000, n), rng.integers(0, 120, n)) if law == 1 else
+                      np.zeros(n, np.int64))
+            b = piece_search_bounds(counts, 768, 128)
+            _check(n, b)
+            # first tile i with 8 W(i) >= k W_total, W(i) = weight in front of tile i + 1 (the kernel counts a tile in when its own
+            # weight reaches the mark): the same boundaries as the prefix search up to that convention
+            w = np.minimum(counts, 768) + 128
+            cw = np.cumsum(w)
+            want = [0] + [int(np.searchsorted(8 * cw, k * int(cw[-1]), side="left")) + 1 for k in range(1, 8)] + [n]
+            assert b == clamp_runs(want, n), (n, law, b, want)
+            grid = 32 * longest_of(b, n)
+            got = sorted(4 * it[0] + it[1] for it in (fwd_item_runs(wg, b) for wg in range(grid)) if it is not None)
+            assert got == list(range(4 * n)), (n, law)
+
+
+# ---- bands of the lean count / emit passes (binning.h: band_geometry, band_plan) ----------------------------------------------------
+MAX_BANDS, SPAN_MAX_HEAD_WORDS = 24, 40 * 1024 - 16 * 64 * 18 - 64
+
+
+def band_geometry(gx, gy, max_head=SPAN_MAX_HEAD_WORDS):
+    band_h = max(1, (gy + 15) // 16)
+    while band_h > 1 and (band_h + 1) * (gx + 2) > max_head:
+        band_h -= 1
+    nbands = (gy + band_h - 1) // band_h
+    return band_h, nbands, nbands <= MAX_BANDS and (band_h + 1) * (gx + 2) <= max_head
+
+
+def band_plan(cnt, nwg):
+    nbands, total = len(cnt), int(sum(cnt))
+    avail = nwg - nbands if nwg > nbands else 0
+    n = [1 + (c * avail // total if total else 0) for c in cnt]
+    first = [0]
+    for v in n:
+        first.append(first[-1] + v)
+    return first
+
+
+def test_band_geometry_and_plan():
+    for gx, gy in [(120, 68), (100, 67), (16, 16), (1, 1), (3, 40), (256, 160), (480, 270), (1023, 300)]:
+        band_h, nbands, ok = band_geometry(gx, gy)
+        assert ok and 1 <= nbands <= MAX_BANDS and band_h * nbands >= gy > band_h * (nbands - 1), (gx, gy, band_h, nbands)
+    assert not band_geometry(1023, 2047)[2]          # beyond 24 bands of what fits the LDS: refused by the host
+    rng = np.random.default_rng(3)
+    for nbands in (1, 2, 14, 24):
+        for nwg in (nbands, nbands + 1, 40, 256):
+            for _ in range(20):
+                cnt = rng.integers(0, 100000, nbands) * (rng.random(nbands) < 0.8)
+                first = band_plan(cnt.tolist(), nwg)
+                sizes = np.diff(first)
+                assert first[0] == 0 and first[-1] <= nwg and sizes.min() >= 1, (cnt, nwg, first)
+                if cnt.sum() and nwg >= 8 * nbands:      # workgroups follow the load: no band more than ~2x over its share
+                    share = cnt / cnt.sum() * (nwg - nbands)
+                    assert np.all(sizes <= share + 1 + 1e-9) and np.all(sizes >= np.floor(share)), (cnt, sizes)
