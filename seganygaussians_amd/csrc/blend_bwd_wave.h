@@ -531,7 +531,11 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         } else {
             item = xcd_grab_runs(queue_ctr, xcd_load_runs(run_bounds), 4u);
         }
-        if (item != 0xFFFFFFFFu) quadrant(item >> 2, item & 3u);
+        if (item != 0xFFFFFFFFu) {
+            MI_XCD_STAMP(false);   // (profiling build: per-XCD start / end stamps, common.h)
+            quadrant(item >> 2, item & 3u);
+            MI_XCD_STAMP(true);
+        }
     }
 }
 

@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(64, C == 32 ? FWD_WAVES32 : FWD_WAVES64) blend
     fwd_zero_fill(zfill, blockIdx.x, gridDim.x, (int)(threadIdx.x & 63));   // (every workgroup, also those without an item)
     uint32_t tile, quad;
     if (!fwd_wave_item(blockIdx.x, ntiles, runs_per_xcd, run_bounds, tile, quad)) return;
+    MI_XCD_STAMP(false);   // (profiling build: per-XCD start / end stamps, common.h)
     const int lane = threadIdx.x & 63;
     const uint32_t tile_x = tile % horizontal_blocks, tile_y = tile / horizontal_blocks;
     const uint32_t px = tile_x * TILE_X + (quad & 1) * 8 + (lane & 7);
@@ -441,6 +442,7 @@ __global__ void __launch_bounds__(64, C == 32 ? FWD_WAVES32 : FWD_WAVES64) blend
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
     }
+    MI_XCD_STAMP(true);
 }
 
 }  // namespace mirast

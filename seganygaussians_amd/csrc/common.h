@@ -20,6 +20,26 @@
 #define MI_ABLATE(bit) (false)
 #endif
 
+// Per-wave time stamps of the blend kernels, PROFILING build only (tools/xcd_stamps.py; mi_rast_xcd_stamps in mi_rast.hip): a wave's
+// first lane stores the constant 100-MHz clock at its start (with the XCD it runs on) and at its end into ITS OWN two words -- plain
+// stores: stamps kept with atomics on sixteen shared words slowed the kernels by half.  The product build compiles the macro to nothing.
+#ifdef MI_RAST_PROFILING
+constexpr unsigned MI_XCD_LOG_WAVES = 1u << 18;
+__device__ unsigned long long g_xcd_log[2 * MI_XCD_LOG_WAVES];   // [2 b] = start << 3 | XCD, [2 b + 1] = end, b = workgroup id
+#define MI_XCD_STAMP(AT_END)                                                                                          \
+    do {                                                                                                              \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < MI_XCD_LOG_WAVES) {                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                           \
+            const unsigned x_ = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; /* HW_REG_XCC_ID */        \
+            g_xcd_log[2u * blockIdx.x + ((AT_END) ? 1u : 0u)] = (AT_END) ? t_ : ((t_ << 3) | x_);                     \
+        }                                                                                                             \
+    } while (0)
+#else
+#define MI_XCD_STAMP(AT_END) \
+    do {                     \
+    } while (0)
+#endif
+
 namespace mirast {
 
 constexpr int R_SLOTS = 64;        // partial sums of R, one per 128-byte line

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "binning.h"
 #include "knn_smooth.h"
@@ -306,7 +307,13 @@ int channel_block(int rem) { return rem >= 64 ? 64 : (rem >= 32 ? 32 : 16); }
 constexpr int FWD_RUNS_PER_XCD = 0;   // forward: m interleaved runs of equal tile counts per XCD; 0: one run per XCD, boundaries from the range scan
 constexpr int RUN_MODEL_CAP = 768;    // range scan: XCD runs of equal sum(min(list length, cap) + fix); 0: equal tile counts
 constexpr int RUN_MODEL_FIX = 128;
-constexpr int BWD_RUNS_FROM_WALKS = 0;   // forward of a view to be differentiated: the backward's runs from what it walked (one more 9-us launch)
+// Forward of a view to be differentiated: the backward's runs from what the forward really WALKED (run_bounds_from_walks_kernel, one more
+// 9-us launch behind the forward blend).  0 (product): never; 1: always; 2: when the range scan's model says the scene's density varies
+// over the image (its longest run exceeds the equal share by more than an eighth).  Round 6 (tools/xcd_stamps.py: per-XCD finish times
+// from per-wave stamps): with the model runs the backward's XCDs finish within 6-7 % of each other on the uniform law (cfg3) and within
+// 21 % on the second law (cfg3s; the model balances the FORWARD: 11-13 %); the exact walks take 1.6 % off that backward (1.099 -> 1.081 ms)
+// and put their launch on the forward: 530.2 / 529.1 / 530.8 views/s for 0 / 2 / 1 -- nothing, so it stays a knob.
+constexpr int BWD_RUNS_FROM_WALKS = 0;
 inline int knob(const char* name, int dflt)
 {
 #ifdef MI_RAST_PROFILING
@@ -937,6 +944,32 @@ size_t mi_rast_binning_layout(int R, size_t* off)
     return c.off;
 }
 
+#ifdef MI_RAST_PROFILING
+// Profiling build only (tools/xcd_stamps.py; not part of include/mi_rast.h): from the blend kernels' per-wave stamps since the last reset,
+// per XCD x: out[x] = latest end of a wave, out[8 + x] = earliest start, out[16 + x] = waves -- ticks of the constant 100-MHz clock.
+int mi_rast_xcd_stamps(unsigned long long* out, int reset)
+{
+    static std::vector<unsigned long long> h(2 * (size_t)MI_XCD_LOG_WAVES);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_xcd_log), h.size() * sizeof(unsigned long long)));
+    for (int k = 0; k < 24; k++) out[k] = 0ull;
+    for (size_t b = 0; b < MI_XCD_LOG_WAVES; b++) {
+        const unsigned long long s0 = h[2 * b], e0 = h[2 * b + 1];
+        if (s0 == 0ull || e0 == 0ull) continue;
+        const int x = (int)(s0 & 7ull);
+        const unsigned long long st = s0 >> 3;
+        out[x] = std::max(out[x], e0);
+        out[8 + x] = out[8 + x] == 0ull ? st : std::min(out[8 + x], st);
+        out[16 + x]++;
+    }
+    if (reset) {
+        std::fill(h.begin(), h.end(), 0ull);
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_log), h.data(), h.size() * sizeof(unsigned long long)));
+    }
+    return MI_RAST_OK;
+}
+#endif
+
 int mi_rast_profile_enable(int on)
 {
     if (on && !profile_events(current_device())) return fail(MI_RAST_ERR_HIP, "hipEventCreate failed");
@@ -1070,8 +1103,10 @@ static int blend_forward_stage(const ViewParams& vp, hipStream_t stream, GeomPtr
         // A view that will be differentiated (the caller asked for the backward's buffers to be left zeroed): the backward blend's
         // XCD runs from what this forward walked (common.h "WORK-balanced runs"; inside the forward blend's stage time)
         const int nt_all = (int)(vp.grid_x * vp.grid_y);
+        const int walk_scan = knob("MI_RAST_BWD_SCAN", BWD_RUNS_FROM_WALKS);
+        const uint32_t equal_share = ((uint32_t)nt_all + 7u) >> 3;
         if (((flags & MI_RAST_PREZERO_BWD) || dL_dcolor_next != nullptr) && nt_all <= BIN_MAX_TILES_TOTAL && !(flags & MI_RAST_EQUAL_RUNS) &&
-            knob("MI_RAST_BWD_SCAN", BWD_RUNS_FROM_WALKS))
+            (walk_scan == 1 || (walk_scan == 2 && img.longest_run > equal_share + (equal_share >> 3))))
             hipLaunchKernelGGL(run_bounds_from_walks_kernel, dim3(1), dim3(1024), ((size_t)nt_all + 1) * sizeof(uint32_t), stream, nt_all,
                                img.tile_nsurv, img.run_bounds);
     }
