@@ -62,7 +62,7 @@ def allreduce_grads_async(tensors: Sequence[Optional[torch.Tensor]], group=None)
     Returns (event, keepalive): `event` is a torch.cuda.Event that fires when the reduced values are in place (None on
     CPU tensors, where the call completes the reduction, and when there is nothing to reduce); `keepalive` must be held
     until the event has been waited for.  Use with rasterizer.set_features_ready_event: in SAGA's feature training the
-    next view's geometry stages (preprocess, depth order, binning, per-tile sort: a quarter of a step) do not depend on
+    next view's geometry stages (preprocess, binning, per-tile sort: a fifth of a step) do not depend on
     the reduced gradients and can run while they travel."""
     ts = [t for t in tensors if t is not None]
     if not ts or not (dist.is_available() and dist.is_initialized()):

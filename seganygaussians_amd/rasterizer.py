@@ -403,7 +403,7 @@ def _check_widths(channels, background, colors, P):
 
 def set_features_ready_event(event) -> None:
     """The next forward of this host thread makes its stream wait for `event` (a recorded torch.cuda.Event, or None to
-    cancel) right before its blend stage; everything before it -- preprocess, depth order, binning, per-tile sort -- only
+    cancel) right before its blend stage; everything before it -- preprocess, binning, per-tile sort -- only
     reads the geometry and runs ahead.  For training loops that optimise colors_precomp alone.  The event is passed to that
     one mi_rast_forward call as an argument (include/mi_rast.h: features_ready_event) and a reference is held until it
     returns; an error in that forward drops it as well."""
