@@ -154,6 +154,11 @@ def main():
                          "(python -m seganygaussians_amd.build --profiling)")
     ap.add_argument("--equal-runs", action="store_true",
                     help="A/B aid: the blend kernels' XCD runs at equal tile counts (MI_RAST_EQUAL_RUNS) instead of equal modelled work")
+    ap.add_argument("--features-only-grad", action="store_true",
+                    help="adds a separately labelled result `features_only_backward` (never the headline): the same fwd+bwd steps with the "
+                         "opt-in features-only backward of the drop-in on (rasterizer.enable_features_only_backward / "
+                         "MI_RAST_FEATURES_ONLY_BACKWARD=1: SAGA's feature training optimises the feature rows only, the reference computes "
+                         "the seven geometry gradients all the same and nobody reads them); with --frozen-geometry also the two opt-ins together")
     ap.add_argument("--frozen-geometry", action="store_true",
                     help="adds a SECOND, separately labelled result `frozen_geometry` (never the headline): the same fwd+bwd steps with the "
                          "opt-in per-camera geometry cache of the drop-in on (rasterizer.GeometryCache: SAGA's feature training optimises the "
@@ -751,6 +756,69 @@ def main():
                           "tensors and the camera are unchanged (content fingerprints; seganygaussians_amd/rasterizer.py: GeometryCache, "
                           "mi_rast_forward_reuse); NOT the headline: `value` recomputes everything every step as the reference does"}
 
+    # ---- features-only backward: a separately labelled figure (never `value`) -----------------------------------------------------
+    feat_only = None
+    if args.features_only_grad and rank == 0 and world == 1 and not fwd_only:
+        def fo_step(rz=rasterizer):
+            for l in leaves:
+                l.grad = None
+            m2 = torch.zeros_like(means3D, requires_grad=True)
+            col_, _ = rz(means3D=means3D, means2D=m2, shs=None, colors_precomp=feats, opacities=opac, scales=scales, rotations=rots,
+                         cov3D_precomp=None)
+            torch.autograd.backward(col_, grad_tensors=dL)
+
+        def fo_run(n, rzs=(rasterizer,)):
+            torch.cuda.synchronize(dev)
+            t0_ = time.perf_counter()
+            for k in range(n):
+                fo_step(rzs[k % len(rzs)])
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0_
+        nfo = max(args.steps, 50)
+        fo_run(5)
+        t_full = fo_run(nfo)                         # the headline's step again, through the same loop
+        g_full = feats.grad.detach().clone()
+        prev_fo = R.enable_features_only_backward(True)
+        try:
+            fo_run(5)
+            t_fo = fo_run(nfo)
+            g_fo = feats.grad.detach().clone()
+            others_unset = all(l.grad is None for l in leaves if l is not feats)
+            _lib.profile_enable(True)   # per-stage HIP events of three un-timed steps (the geometry backward does not run: no stage)
+            st_fo = {k: 0.0 for k in _lib.MI_STAGES if k != "geom_bwd"}
+            for _ in range(3):
+                fo_step()
+                torch.cuda.synchronize(dev)
+                ms_ = _lib.profile_read()
+                for k in st_fo:
+                    st_fo[k] += ms_[k] / 3
+            _lib.profile_enable(False)
+            both = None
+            if args.frozen_geometry:
+                nv = max(1, args.views)
+                cams_f = [scenes.orbit_camera(W, H, cfg["focal"], 0.02 * k, 0.01 * k) for k in range(nv)]
+                rasts = [GaussianRasterizer(settings._replace(viewmatrix=t(c_.viewmatrix), projmatrix=t(c_.projmatrix), campos=t(c_.campos),
+                                                              tanfovx=c_.tanfovx, tanfovy=c_.tanfovy)) for c_ in cams_f]
+                gc_ = R.enable_geometry_cache()
+                gc_.clear()
+                fo_run(nv, rasts)                    # first visits: fill the cache
+                t_both = fo_run(nv * max(2, args.frozen_passes), rasts)
+                R.disable_geometry_cache(drop=True)
+                both = round(nv * max(2, args.frozen_passes) / t_both, 3)
+        finally:
+            R.enable_features_only_backward(prev_fo)
+        scale_ = float(g_full.abs().max())
+        feat_only = {"views_per_s": round(nfo / t_fo, 3), "ms_per_step": round(1e3 * t_fo / nfo, 4),
+                     "views_per_s_default_backward_same_loop": round(nfo / t_full, 3), "steps": nfo,
+                     "dL_dfeatures_max_abs_diff_vs_default": float(f"{float((g_fo - g_full).abs().max()):.3g}"),
+                     "dL_dfeatures_max_abs": float(f"{scale_:.3g}"), "other_gradients_unset": bool(others_unset),
+                     "stages_ms": ({k: round(v, 4) for k, v in st_fo.items()} if isinstance(st_fo, dict) else None),
+                     "views_per_s_with_frozen_geometry_all_hits": both,
+                     "what": "opt-in (rasterizer.enable_features_only_backward / MI_RAST_FEATURES_ONLY_BACKWARD=1; automatic when autograd asks "
+                             "for the colour gradient alone): the backward blend computes dL_dcolors_precomp only -- no feature rows read, no "
+                             "dL/dalpha, no moments, no packed-field atomics -- and the geometry backward does not run (include/mi_rast.h: "
+                             "MI_RAST_BWD_FEATURES_ONLY); NOT the headline: `value` computes all eight gradients every step as the reference does"}
+
     if rank == 0:
         names = {"cfg3": "train views/sec (fwd+bwd), 1080p, 1M Gaussians, 32-D features",
                  "cfg3s": "train views/sec (fwd+bwd), 1080p, 1M Gaussians, 32-D features",
@@ -783,6 +851,8 @@ def main():
             out["reference_on_gpu"] = ref_on_gpu
         if frozen is not None:
             out["frozen_geometry"] = frozen
+        if feat_only is not None:
+            out["features_only_backward"] = feat_only
     phase("reporting")
     state["solo"] = False
     if args.dump_grads and not fwd_only:

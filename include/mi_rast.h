@@ -90,6 +90,14 @@ extern "C" {
                                   tile_ranges_kernel -- because the dispatcher deals workgroups to the XCDs whatever their progress and
                                   real scenes' density varies over the image; with this flag at equal tile counts (rounds 2-4).
                                   Results are the same either way (the order of the atomic sums apart) */
+#define MI_RAST_BWD_FEATURES_ONLY 512 /* EXTENSION, mi_rast_backward only: the caller wants dL_dcolor and NOTHING else -- SAGA's contrastive feature
+                                  training optimises the feature rows alone (scene/gaussian_model_ff.py:154-162); the reference computes the geometry
+                                  gradients all the same and nobody reads them.  dL_dcolor[g] = sum over the pairs of alpha T dL_dpix needs alpha and T
+                                  of every pair and no more: the backward blend then reads no feature row, forms no dL/dalpha, no moments, issues no
+                                  packed-field atomics (a third of its atomic requests), and the per-Gaussian geometry backward does not run.  Every
+                                  other dL_d* pointer may be NULL and is left untouched.  Needs colors_precomp != NULL and a channel count that is a
+                                  multiple of 16 (mi_rast_features_only_supported); dL_dcolor equals the default mode's up to the order of the atomic
+                                  sums.  seganygaussians_amd/rasterizer.py: enable_features_only_backward() / MI_RAST_FEATURES_ONLY_BACKWARD=1 */
 
 /* Replaces std::function<char*(size_t)> (CF/rasterize_points.cu:27-33): must return a device
  * pointer to at least nbytes bytes (256-B aligned), valid until the caller frees it. */
@@ -218,6 +226,8 @@ int mi_rast_forward_reuse(
     const float* mask, float* out_color, float* out_mask, float* out_depth,
     int flags, void* features_ready_event, float* dL_dcolor_next, void* stream);
 int mi_rast_last_longest_run(void);
+/* 1 if mi_rast_backward honours MI_RAST_BWD_FEATURES_ONLY for this channel count (a multiple of 16), else 0. */
+int mi_rast_features_only_supported(int channels);
 /* 64-bit content fingerprints of n <= 8 device arrays of 4-byte words (position-dependent word hashes, summed): out[k] [host].
  * Synchronous (one kernel on `stream`, then the calling thread waits for the stream). */
 int mi_rast_fingerprint(int n, const void* const* ptrs, const size_t* nbytes, uint64_t* out /* [host] */, void* stream);

@@ -17,10 +17,11 @@ MI_RAST_FULL_LISTS, MI_RAST_F32_BLEND, MI_RAST_NO_CULL, MI_RAST_FAST_EXP, MI_RAS
 MI_RAST_PREZERO_BWD = 64   # forward + the one backward of that forward (include/mi_rast.h)
 MI_RAST_EXACT_EXP = 128    # forward blend with expf for every pair instead of the hybrid form (include/mi_rast.h)
 MI_RAST_EQUAL_RUNS = 256   # A/B aid: XCD runs of equal tile counts in both blend kernels instead of equal modelled work (include/mi_rast.h)
+MI_RAST_BWD_FEATURES_ONLY = 512   # mi_rast_backward: dL_dcolor alone (extension, include/mi_rast.h)
 MI_STAGES = ["preprocess", "tile_scan", "emit", "tile_sort", "blend_fwd", "blend_bwd", "geom_bwd"]
 
 EXPORTS = [
-    "mi_rast_forward", "mi_rast_forward_reuse", "mi_rast_last_longest_run", "mi_rast_fingerprint", "mi_rast_backward", "mi_rast_mark_visible", "mi_rast_mask_forward",
+    "mi_rast_forward", "mi_rast_forward_reuse", "mi_rast_last_longest_run", "mi_rast_fingerprint", "mi_rast_features_only_supported", "mi_rast_backward", "mi_rast_mark_visible", "mi_rast_mask_forward",
     "mi_rast_mask_backward", "mi_rast_last_error", "mi_rast_version", "mi_rast_supported_channels",
     "mi_rast_get_higher_msb", "mi_rast_geometry_layout", "mi_rast_image_layout", "mi_rast_binning_layout",
     "mi_rast_profile_enable", "mi_rast_profile_read",
@@ -64,6 +65,8 @@ def load():
     L.mi_rast_fingerprint.argtypes = [i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), vp]
     L.mi_rast_last_longest_run.restype = i
     L.mi_rast_last_longest_run.argtypes = []
+    L.mi_rast_features_only_supported.restype = i
+    L.mi_rast_features_only_supported.argtypes = [i]
     L.mi_rast_backward.restype = i
     L.mi_rast_backward.argtypes = [i, i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]

@@ -1224,6 +1224,8 @@ int mi_rast_last_longest_run(void)
     return dev < 0 ? 0 : g_last_longest_run[dev];
 }
 
+int mi_rast_features_only_supported(int channels) { return channels >= 16 && channels <= 256 && channels % 16 == 0 ? 1 : 0; }
+
 int mi_rast_backward(int P, int D, int M, int channels, int R, const float* background, int width, int height,
                      const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                      float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -1241,6 +1243,10 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 1 .. 256)");
     const bool maskgrad = dL_dmask != nullptr;
     if (maskgrad && (channels != 3 || !dL_dout_mask)) return fail(MI_RAST_ERR_INVALID, "mask gradient needs 3 channels and dL_dout_mask");
+    // EXTENSION (mi_rast.h): dL_dcolor alone -- the blend kernel in its GEOM = false form, no geometry backward
+    const bool feat_only = (flags & MI_RAST_BWD_FEATURES_ONLY) != 0;
+    if (feat_only && (!mi_rast_features_only_supported(channels) || colors_precomp == nullptr || maskgrad || dL_dcolor == nullptr))
+        return fail(MI_RAST_ERR_INVALID, "MI_RAST_BWD_FEATURES_ONLY needs colors_precomp, dL_dcolor and a channel count that is a multiple of 16");
 
     const ViewParams vp = make_view(viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, width, height);
 
@@ -1251,7 +1257,10 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     {
         StageTimer t(stream, MI_STAGE_BLEND_BWD);
         // (MI_RAST_PREZERO_BWD: the forward of this view left the block zeroed, and no backward has run on it since)
-        if (!(flags & MI_RAST_PREZERO_BWD)) HIP_TRY(hipMemsetAsync(geom.bwd_pack, 0, bwd_pack_bytes(P), stream));
+        // (features only: the packed fields are not used, the work-queue counters behind them are)
+        if (!(flags & MI_RAST_PREZERO_BWD))
+            HIP_TRY(hipMemsetAsync(feat_only ? (void*)(geom.bwd_pack + (size_t)P * 8) : (void*)geom.bwd_pack, 0,
+                                   bwd_pack_bytes(P) - (feat_only ? (size_t)P * 8 * sizeof(float) : 0), stream));
         uint32_t* queue_ctr = reinterpret_cast<uint32_t*>(geom.bwd_pack + (size_t)P * 8);   // one set of eight counters per channel block
         const float* bg_blk = background;
         const float* colors_blk = color_ptr;
@@ -1283,7 +1292,35 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
             else launch_blend_bwd<64, false>(vp, stream, img, bin, geom, color_ptr, background, dL_dpix, nullptr, dL_dcolor, xexp);
         } else
 #endif
-        if (maskgrad) LAUNCH_BWD_WAVE(16, 3, true);
+        if (feat_only) {
+            // one launch per channel block of 64 / 32 / 16 channels, GEOM = false: alpha, T, dF = W^T dL and the feature-row atomics
+#define LAUNCH_BWD_FEAT_(C_, XE, ST)                                                                                             \
+    hipLaunchKernelGGL((blend_bwd_wave_kernel<C_, C_, false, XE, ST, false>), dim3(32u * xcd_static_len_max(nt_) + 4u * xcd_queued_tiles_max(nt_)), \
+                       dim3(64), 0, stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk,      \
+                       colors_blk, img.final_T, img.n_contrib, dpix_blk, (const float*)nullptr, geom.bwd_pack, dcolor_blk, queue_ctr, cstride,  \
+                       cr_blk, img.run_bounds)
+#define LAUNCH_BWD_FEAT(C_)                                                                  \
+    do {                                                                                     \
+        if (cstride == C_) { if (xexp) LAUNCH_BWD_FEAT_(C_, true, false); else LAUNCH_BWD_FEAT_(C_, false, false); } \
+        else { if (xexp) LAUNCH_BWD_FEAT_(C_, true, true); else LAUNCH_BWD_FEAT_(C_, false, true); }                 \
+    } while (0)
+            const size_t HW = (size_t)width * height;
+            for (int c0 = 0; c0 < channels;) {
+                const int cb = channel_block(channels - c0);
+                bg_blk = background + c0;
+                colors_blk = color_ptr + c0;
+                dpix_blk = dL_dpix + (size_t)c0 * HW;
+                dcolor_blk = dL_dcolor + c0;
+                cr_blk = cb;
+                if (cb == 64) LAUNCH_BWD_FEAT(64);
+                else if (cb == 32) LAUNCH_BWD_FEAT(32);
+                else LAUNCH_BWD_FEAT(16);
+                queue_ctr += 8 * XCD_QUEUE_STRIDE;
+                c0 += cb;
+            }
+#undef LAUNCH_BWD_FEAT
+#undef LAUNCH_BWD_FEAT_
+        } else if (maskgrad) LAUNCH_BWD_WAVE(16, 3, true);
         else if (channels == 3) LAUNCH_BWD_WAVE(16, 3, false);
         else {
             // one launch per channel block: the feature gradient of the block, and the block's share of the geometry gradients
@@ -1310,6 +1347,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     }
     STAGE_CHECK("render backward");
 
+    if (feat_only) return MI_RAST_OK;
     const float* cov3D_ptr = (cov3D_precomp != nullptr) ? cov3D_precomp : geom.cov3D;  // rasterizer_impl.cu:411
     {
         StageTimer t(stream, MI_STAGE_GEOM_BWD);

@@ -269,6 +269,41 @@ if os.environ.get("MI_RAST_GEOMETRY_CACHE", "") not in ("", "0"):
     enable_geometry_cache(int((64 if _gib == 1.0 else _gib) * (1 << 30)))
 
 
+# ---- features-only backward (EXTENSION, include/mi_rast.h: MI_RAST_BWD_FEATURES_ONLY) ------------------------------------------
+# SAGA's contrastive feature training optimises `_point_features` alone (scene/gaussian_model_ff.py:154-162), but every parameter of
+# its model requires grad and the renderer creates `screenspace_points` with requires_grad=True (gaussian_renderer/__init__.py:308):
+# autograd asks the rasterizer for all eight gradients, the reference computes them, and nobody reads seven of them.
+#   * AUTOMATIC, always on: when autograd itself says that only colors_precomp needs a gradient (ctx.needs_input_grad), the backward
+#     computes that one alone -- plain autograd semantics, nothing to opt into.
+#   * OPT-IN, for unchanged reference scripts: enable_features_only_backward() / MI_RAST_FEATURES_ONLY_BACKWARD=1 makes every backward
+#     of the feature rasterizer return dL_dcolors_precomp and None for the rest (means2D.grad, xyz.grad, ... stay unset).
+# Either way the result equals the default backward's dL_dcolors up to the order of the atomic sums.  Never used by the headline
+# benchmark: the reference's step computes all eight gradients, and so does bench.py's.
+_features_only_backward = os.environ.get("MI_RAST_FEATURES_ONLY_BACKWARD", "") not in ("", "0")
+
+
+def enable_features_only_backward(on=True):
+    """Opt-in: backward passes through the rasterizer produce the gradient of colors_precomp only (see above); returns the previous
+    setting.  Applies to calls with precomputed colours / features of a width that is a multiple of 16; others run the full backward."""
+    global _features_only_backward
+    prev, _features_only_backward = _features_only_backward, bool(on)
+    return prev
+
+
+def features_only_backward_enabled():
+    return _features_only_backward
+
+
+def _features_only_applies(channels, colors_precomp, needs_input_grad, debug):
+    """needs_input_grad: (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, ...) of the Function."""
+    if debug or colors_precomp is None or colors_precomp.numel() == 0 or not needs_input_grad[3]:
+        return False
+    if not _lib.load().mi_rast_features_only_supported(int(channels)):
+        return False
+    others = [needs_input_grad[k] for k in (0, 1, 2, 4, 5, 6, 7)]
+    return _features_only_backward or not any(others)
+
+
 _NOCACHE_FLAGS = _lib.MI_RAST_FULL_LISTS | _lib.MI_RAST_NO_CULL | _lib.MI_RAST_VERIFY_LISTS | _lib.MI_RAST_TILE_FWD | _lib.MI_RAST_F32_BLEND
 
 
@@ -419,12 +454,15 @@ def _flags_of(geomBuffer, flags):
 def rasterize_gaussians_backward_native(channels, with_mask_depth, background, means3D, radii, colors, scales,
                                         rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
                                         tan_fovy, dL_dout_color, dL_dout_mask, sh, degree, campos, geomBuffer, R,
-                                        binningBuffer, imageBuffer, debug, flags=None, prezeroed=None, pack_zeroed=None):
+                                        binningBuffer, imageBuffer, debug, flags=None, prezeroed=None, pack_zeroed=None,
+                                        features_only=False):
     """RasterizeGaussiansBackwardCUDA (CF/rasterize_points.cu:117-196; DEPTH/rasterize_points.cu).
 
     prezeroed: the zero-filled (P, channels) tensor the forward of THESE buffers produced with prezero=True, not used by any
     backward before: it becomes dL_dcolors.  pack_zeroed: that forward also left the packed field gradients in its geometry
-    buffer zeroed (None: as `prezeroed`): their fill is skipped."""
+    buffer zeroed (None: as `prezeroed`): their fill is skipped.
+    features_only (extension, include/mi_rast.h: MI_RAST_BWD_FEATURES_ONLY): dL_dcolors alone is computed and returned in its place
+    of the tuple, None everywhere else."""
     L = _lib.load()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -446,6 +484,29 @@ def rasterize_gaussians_backward_native(channels, with_mask_depth, background, m
     if with_mask_depth:
         shapes.append(("dL_dmask", (P, 1)))   # DEPTH/rasterize_points.cu:167: torch::zeros({P, 1})
     shapes = [x for x in shapes if x[0] not in ("dL_dcolors", "dL_dsh")]
+    if features_only:
+        if with_mask_depth or colors.numel() == 0:
+            raise RuntimeError("features_only backward needs precomputed colours and the plain (not DEPTH) rasterizer")
+        if pack_zeroed is None:
+            pack_zeroed = prezeroed is not None
+        if prezeroed is not None and (tuple(prezeroed.shape) != (P, channels) or prezeroed.device != dev):
+            prezeroed = None
+        dL_dcolors = prezeroed if prezeroed is not None else torch.zeros((P, channels), **o)
+        if P != 0:
+            t = [_contig(x) for x in (background, means3D, colors, viewmatrix, projmatrix, campos, dL_dout_color, radii)]
+            bg_c, m3_c, col_c, vm_c, pm_c, cp_c, dpix_c, radii_c = t
+            with torch.cuda.device(dev):
+                rc = L.mi_rast_backward(
+                    P, int(degree), 0, int(channels), int(R), _dev_ptr(bg_c, "bg", dev), W, H,
+                    _dev_ptr(m3_c, "means3D", dev), None, _dev_ptr(col_c, "colors_precomp", dev), None, float(scale_modifier), None,
+                    None, _dev_ptr(vm_c, "viewmatrix", dev), _dev_ptr(pm_c, "projmatrix", dev), _dev_ptr(cp_c, "campos", dev),
+                    float(tan_fovx), float(tan_fovy), _dev_ptr(radii_c, "radii", dev, torch.int32), geomBuffer.data_ptr(),
+                    binningBuffer.data_ptr(), imageBuffer.data_ptr(), _dev_ptr(dpix_c, "dL_dout_color", dev), None,
+                    None, None, None, dL_dcolors.data_ptr(), None, None, None, None, None, None, 0,
+                    int(_flags_of(geomBuffer, flags)) | _lib.MI_RAST_BWD_FEATURES_ONLY | (_lib.MI_RAST_PREZERO_BWD if pack_zeroed else 0),
+                    _stream_ptr(dev))
+            _check(rc)
+        return None, dL_dcolors, None, None, None, None, None, None
     sizes = []
     for _n, shp in shapes:
         n = 1
@@ -632,11 +693,14 @@ def _make_plain(channels):
             prezeroed, ctx.mi_prezero = ctx.mi_prezero, None   # (a second backward through a retained graph fills for itself)
             pack_zeroed, ctx.mi_pack_zeroed = ctx.mi_pack_zeroed, False
 
+            feat_only = _features_only_applies(channels, colors_precomp, ctx.needs_input_grad, rs.debug)
+
             def call():
                 (bg, m3, rad, col, sc, rot, smod, cov, vm, pm, tx, ty, gout, sh_, deg, cp, gb, nr, bb, ib, dbg) = args
                 return rasterize_gaussians_backward_native(channels, False, bg, m3, rad, col, sc, rot, smod, cov, vm,
                                                            pm, tx, ty, gout, None, sh_, deg, cp, gb, nr, bb, ib, dbg,
-                                                           flags=ctx.mi_flags, prezeroed=prezeroed, pack_zeroed=pack_zeroed)
+                                                           flags=ctx.mi_flags, prezeroed=prezeroed, pack_zeroed=pack_zeroed,
+                                                           features_only=feat_only)
 
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
