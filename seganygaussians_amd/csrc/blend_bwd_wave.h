@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
 
     __shared__ BwdPar s_par[CHK];                 // the chunk's 16 records
     __shared__ float4 s_feat4[GEOM ? FEAT4 : 1];  // the chunk's 16 feature rows (GEOM = false: none are read)
-    __shared__ float4 s_wu4[2 * CHK * WROW / 4];  // S / w rows | u rows   (prologue: gradient-image staging; after step 3: moments)
+    __shared__ float4 s_wu4[(GEOM ? 2 : 1) * CHK * WROW / 4];  // S / w rows | u rows   (prologue: gradient-image staging; after step 3: moments)
+    // (GEOM = false: w rows alone -- the gradient image is then staged 16 channels at a time at a row stride of 17 floats)
     __shared__ uint2 s_queue[QCAP];               // {walk index, entry = Gaussian id | quadrant mask << 28}
 
     // One (tile, quadrant) item: everything below.  Which item a wave gets is decided at the end of the kernel.
@@ -141,14 +142,16 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     float bg_dot_dpixel = 0.f;  // bg . dL of this lane's own pixel (backward.cu:533-535)
     {
         float* stage = reinterpret_cast<float*>(s_wu4);
-        constexpr int PASS = C < 32 ? C : 32;  // channels per pass through the staging rows
+        constexpr int PASS = !GEOM ? 16 : (C < 32 ? C : 32);  // channels per pass through the staging rows
+        constexpr int SROW = !GEOM ? 17 : DLROW;              // staging row stride (floats)
+        static_assert(GEOM || CHK * WROW >= 64 * SROW, "gradient-image staging must fit in the w rows");
 #pragma unroll
         for (int h = 0; h < C / PASS; h++) {
 #pragma unroll
             for (int c = 0; c < PASS; c++) {
                 const float v = inside ? dLpix[PASS * h + c] : 0.f;
                 if (GEOM && PASS * h + c < cr) bg_dot_dpixel += bg_color[PASS * h + c] * v;
-                stage[lane * DLROW + c] = v;
+                stage[lane * SROW + c] = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             // lanes whose CPL channels lie in this pass (all of them when C <= 32)
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             for (int pb = 0; pb < 4; pb++)
 #pragma unroll
                 for (int s = 0; s < CPL; s++) {
-                    float v = stage[(16 * pb + n16) * DLROW + (mine ? c0 + s : s)];
+                    float v = stage[(16 * pb + n16) * SROW + (mine ? c0 + s : s)];
                     if (MASKGRAD && CPL * kq + s == CR) v = 0.f;  // the mask plane is no part of S
                     if (C <= 32 || mine) dLB[pb][s] = v;
                 }
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
 #pragma unroll
             for (int s = 0; s < 16; s++)
 #pragma unroll
-                for (int nb = 0; nb < PASS / 16; nb++) dLT[(PASS / 16) * h + nb][s] = stage[(16 * kq + s) * DLROW + 16 * nb + n16];
+                for (int nb = 0; nb < PASS / 16; nb++) dLT[(PASS / 16) * h + nb][s] = stage[(16 * kq + s) * SROW + 16 * nb + n16];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
     }
