@@ -66,20 +66,33 @@ def _write_dataset(root, seed=0):
             f.write(f"{i + 1} {p[0]} {p[1]} {p[2]} {c[0]} {c[1]} {c[2]} 0.5 1 0\n")
 
 
-@pytest.mark.parametrize("geometry_cache", [False, True])
-def test_reference_training_and_rendering_scripts_end_to_end(tmp_path, geometry_cache):
+@pytest.mark.parametrize("geometry_cache,features_only", [(False, False), (True, False), (True, True)])
+def test_reference_training_and_rendering_scripts_end_to_end(tmp_path, geometry_cache, features_only):
     """geometry_cache=True: the same scripts with the opt-in frozen-geometry reuse switched on (rasterizer.GeometryCache): the
     training loop revisits its cameras with unchanged geometry -- activation outputs, new tensors per call: hits by content --,
-    and every check below (losses, files, the rendered feature image against the oracle) must hold unchanged."""
+    and every check below (losses, files, the rendered feature image against the oracle) must hold unchanged.
+    features_only=True: also the opt-in features-only backward (rasterizer.enable_features_only_backward): the loop optimises
+    `_point_features` alone (scene/gaussian_model_ff.py:154-162) -- every backward of the training must take that form, and the
+    same checks hold."""
     from seganygaussians_amd import rasterizer as R_
     cache = None
     if geometry_cache:
         cache = R_.enable_geometry_cache(4 << 30)
         cache.clear()
+    prev_fo = R_.enable_features_only_backward(features_only)
+    calls, orig = [], R_.rasterize_gaussians_backward_native
+
+    def spy(*a, **k):
+        calls.append(bool(k.get("features_only")))
+        return orig(*a, **k)
+    R_.rasterize_gaussians_backward_native = spy
     try:
         _run_reference_scripts(tmp_path, cache)
     finally:
+        R_.rasterize_gaussians_backward_native = orig
+        R_.enable_features_only_backward(prev_fo)
         R_.disable_geometry_cache(drop=True)
+    assert len(calls) >= 20 and all(c == features_only for c in calls), calls
 
 
 def _run_reference_scripts(tmp_path, cache):

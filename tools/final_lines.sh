@@ -10,6 +10,6 @@ python bench.py --config cfg5 --ref-on-gpu > $OUT/cfg5.log 2>&1
 python bench.py --config cfg1 > $OUT/cfg1.log 2>&1
 python bench.py --dist-single --steps 10 --warmup 3 > $OUT/dist.log 2>&1
 python bench.py --dist-single --rs-ag --steps 10 --warmup 3 > $OUT/dist_rsag.log 2>&1
-python bench.py --frozen-geometry --views 16 --no-cpu-baseline > $OUT/frozen.log 2>&1
-python bench.py --config cfg5 --frozen-geometry --views 8 --no-cpu-baseline > $OUT/frozen_cfg5.log 2>&1
+python bench.py --frozen-geometry --features-only-grad --views 16 --no-cpu-baseline > $OUT/frozen.log 2>&1
+python bench.py --config cfg5 --frozen-geometry --features-only-grad --views 8 --no-cpu-baseline > $OUT/frozen_cfg5.log 2>&1
 [ -n "$WITH_FASTEXP" ] && python bench.py --fast-exp --no-cpu-baseline > $OUT/fastexp.log 2>&1
