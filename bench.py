@@ -609,7 +609,12 @@ def main():
                     rem -= cb
                 d.update({"rows": rows, "atomic_segment_requests": segs * rows,
                           "atomic_unit_frac": round(segs * rows / sec / ATOMIC_SEGMENT_RATE, 4),
-                          "atomic_segment_rate_peak": ATOMIC_SEGMENT_RATE})
+                          "atomic_segment_rate_peak": ATOMIC_SEGMENT_RATE,
+                          # the rate this launch ran at, beside what a form of this kernel with nothing but its atomics left reaches
+                          # with conflict-free random rows (profiles/r06_bwd_atomics.md: 15.5 G/s; real rows 13.4 - 14.5) -- the
+                          # 20 G/s above is that of waves that issue atomics and do nothing else (tools/atomic_bench.hip)
+                          "atomic_segment_rate": round(segs * rows / sec, 0), "atomic_segment_rate_in_kernel_ceiling": 15.5e9,
+                          "atomic_unit_frac_of_in_kernel_ceiling": round(segs * rows / sec / 15.5e9, 4)})
             return d
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": tr(dom),
