@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_rast.so")
 PROF_LIB_PATH = os.path.join(_HERE, "libmi_rast_prof.so")
 SRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["mi_rast.hip", "common.h", "cull.h", "geometry.h", "binning.h", "knn_smooth.h", "knn.h", "blend_fwd.h", "blend_fwd_split.h", "blend_fwd_wave.h", "blend_fwd_x3.h", "blend_bwd.h", "blend_bwd_shared.h", "blend_bwd_wave.h", "contrastive.h"]
+SOURCES = ["mi_rast.hip", "common.h", "cull.h", "geometry.h", "binning.h", "knn_smooth.h", "knn.h", "blend_fwd.h", "blend_fwd_split.h", "blend_fwd_wave.h", "blend_fwd_x3.h", "blend_bwd.h", "blend_bwd_shared.h", "blend_bwd_wave.h", "blend_bwd_feat.h", "contrastive.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "mi_rast.h")
 HEADERS = [os.path.join(os.path.dirname(_HERE), "include", h) for h in ("mi_rast.h", "mi_knn.h", "mi_knn_smooth.h", "mi_contrastive.h")]
 

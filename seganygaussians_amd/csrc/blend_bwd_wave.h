@@ -52,10 +52,7 @@ struct BwvCfg {
 // (1 .. 15) of a 16-channel block are real -- the last block of a feature whose width is no multiple of 16, the reference compiles
 // ANY NUM_CHANNELS (config_contrastive_f.h:15) -- with rows `cstride_arg` floats apart).
 // STRIDED: rows of `colors` / `dL_dcolors` are `cstride_arg` floats apart (one channel block of a wider feature); otherwise CR.
-// GEOM = false (mi_rast.h: MI_RAST_BWD_FEATURES_ONLY): only dL/dfeature is wanted -- dF = W^T dL needs alpha and T of every pair and
-// nothing else: no S contraction (no feature rows are read at all), no dL/dalpha recurrence, no moments, no packed field atomics;
-// what is left is the record gather, the alpha / T recurrence, 32 * C / 32 matrix instructions and the feature-row atomics per chunk.
-template <int C, int CR = C, bool MASKGRAD = false, bool XEXP = false, bool STRIDED = false, bool GEOM = true>
+template <int C, int CR = C, bool MASKGRAD = false, bool XEXP = false, bool STRIDED = false>
 __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ blend_list, const BlendRec* __restrict__ index_rec,
     const uint32_t* __restrict__ tile_nsurv, int W, int H, uint32_t horizontal_blocks, uint32_t ntiles, const float* __restrict__ bg_color,
@@ -80,12 +77,10 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     static_assert(CR != 0 || STRIDED, "a partial block is a block of a wider (or narrower) feature: its row stride is an argument");
     static_assert(!MASKGRAD || CR == 3, "the mask gradient belongs to the RGB (DEPTH variant) kernel");
     static_assert(2 * CHK * WROW >= 64 * DLROW, "gradient-image staging must fit in the w/u rows");
-    static_assert(GEOM || (CR == C && !MASKGRAD), "the features-only form serves full channel blocks of a feature");
 
     __shared__ BwdPar s_par[CHK];                 // the chunk's 16 records
-    __shared__ float4 s_feat4[GEOM ? FEAT4 : 1];  // the chunk's 16 feature rows (GEOM = false: none are read)
-    __shared__ float4 s_wu4[(GEOM ? 2 : 1) * CHK * WROW / 4];  // S / w rows | u rows   (prologue: gradient-image staging; after step 3: moments)
-    // (GEOM = false: w rows alone -- the gradient image is then staged 16 channels at a time at a row stride of 17 floats)
+    __shared__ float4 s_feat4[FEAT4];             // the chunk's 16 feature rows
+    __shared__ float4 s_wu4[2 * CHK * WROW / 4];  // S / w rows | u rows   (prologue: gradient-image staging; after step 3: moments)
     __shared__ uint2 s_queue[QCAP];               // {walk index, entry = Gaussian id | quadrant mask << 28}
 
     // One (tile, quadrant) item: everything below.  Which item a wave gets is decided at the end of the kernel.
@@ -142,35 +137,31 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
     float bg_dot_dpixel = 0.f;  // bg . dL of this lane's own pixel (backward.cu:533-535)
     {
         float* stage = reinterpret_cast<float*>(s_wu4);
-        constexpr int PASS = !GEOM ? 16 : (C < 32 ? C : 32);  // channels per pass through the staging rows
-        constexpr int SROW = !GEOM ? 17 : DLROW;              // staging row stride (floats)
-        static_assert(GEOM || CHK * WROW >= 64 * SROW, "gradient-image staging must fit in the w rows");
+        constexpr int PASS = C < 32 ? C : 32;  // channels per pass through the staging rows
 #pragma unroll
         for (int h = 0; h < C / PASS; h++) {
 #pragma unroll
             for (int c = 0; c < PASS; c++) {
                 const float v = inside ? dLpix[PASS * h + c] : 0.f;
-                if (GEOM && PASS * h + c < cr) bg_dot_dpixel += bg_color[PASS * h + c] * v;
-                stage[lane * SROW + c] = v;
+                if (PASS * h + c < cr) bg_dot_dpixel += bg_color[PASS * h + c] * v;
+                stage[lane * DLROW + c] = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             // lanes whose CPL channels lie in this pass (all of them when C <= 32)
             const bool mine = (CPL * kq) / PASS == h;
             const int c0 = (CPL * kq) % PASS;
-            if constexpr (GEOM) {
 #pragma unroll
             for (int pb = 0; pb < 4; pb++)
 #pragma unroll
                 for (int s = 0; s < CPL; s++) {
-                    float v = stage[(16 * pb + n16) * SROW + (mine ? c0 + s : s)];
+                    float v = stage[(16 * pb + n16) * DLROW + (mine ? c0 + s : s)];
                     if (MASKGRAD && CPL * kq + s == CR) v = 0.f;  // the mask plane is no part of S
                     if (C <= 32 || mine) dLB[pb][s] = v;
                 }
-            }
 #pragma unroll
             for (int s = 0; s < 16; s++)
 #pragma unroll
-                for (int nb = 0; nb < PASS / 16; nb++) dLT[(PASS / 16) * h + nb][s] = stage[(16 * kq + s) * SROW + 16 * nb + n16];
+                for (int nb = 0; nb < PASS / 16; nb++) dLT[(PASS / 16) * h + nb][s] = stage[(16 * kq + s) * DLROW + 16 * nb + n16];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
     }
@@ -242,7 +233,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             curq = reinterpret_cast<const uint2*>(index_rec + gq)[qq];
         }
 #pragma unroll
-        for (int k = 0; k < (GEOM ? NK : 0); k++) {
+        for (int k = 0; k < NK; k++) {
             const int e = l + 64 * k;
             const int g = min(e / F4, n - 1), part = e % F4;
             const size_t gid = (size_t)(s_queue[(qh + g) & (QCAP - 1)].y & ID_MASK);
@@ -293,7 +284,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             const int dst = qq == 0 ? 0 : (qq == 1 ? 24 : (qq == 2 ? 8 : 16));
             *reinterpret_cast<float2*>(reinterpret_cast<char*>(&s_par[rq]) + dst) = v;
 #pragma unroll
-            for (int k = 0; k < (GEOM ? NK : 0); k++) {
+            for (int k = 0; k < NK; k++) {
                 const int e = lane + 64 * k;
                 const int g = e / F4, part = e % F4;
                 float4 f = featpf[k];
@@ -312,7 +303,6 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
         // ---- 3. S = F . dL^T  (16 rows x 64 pixels, K = C channels); lane (n16, kq) feeds row n16
-        if constexpr (GEOM) {
         v4f sacc[4];
         {
             float fa[CPL];
@@ -340,7 +330,6 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) my_wa[(4 * kq + r) * WROW + 16 * pb + n16] = sacc[pb][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        }
 
         // ---- 4. scalar recurrences (lane = pixel), back to front.  Row parameters arrive by LDS broadcast reads.
         // A row that does not blend into this pixel runs the same arithmetic with alpha = 0: T, R stay put, w = u = 0.
@@ -402,35 +391,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
                 my_ua[rr * WROW + lane] = tG[k] * (dS * Tk[k]);
             }
         };
-        // GEOM = false: alpha and T alone, w = alpha T; four rows per reciprocal whatever the background (its term belongs to
-        // dL/dalpha).  A padding row of the wave's last chunk is never valid: alpha = 0, w = 0, T stays put.
-        auto row_group4_w = [&](const int r0) __attribute__((always_inline)) {
-            float al[4], om[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int rr = r0 + k;
-                const float4 p0 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar));
-                const float4 p1 = *reinterpret_cast<const float4*>(par_bytes + rr * (int)sizeof(BwdPar) + 16);
-                const float dx = p0.x - pixfx, dy = p0.y - pixfy;
-                const float power = gauss_power(p0.z, p0.w, p1.x, dx, dy);
-                const float G = gauss_exp<XEXP>(power);
-                const float t0 = ((__float_as_int(p1.z) < last4) && power <= 0.0f) ? p1.y * G : 0.f;
-                al[k] = alpha_clamp(t0 >= ALPHA_CUT ? t0 : 0.f);
-                om[k] = 1.f - al[k];
-            }
-            float Tk[4];
-            Tk[3] = T * rcp_refined((om[0] * om[1]) * (om[2] * om[3]));
-            Tk[2] = Tk[3] * om[3];
-            Tk[1] = Tk[2] * om[2];
-            Tk[0] = Tk[1] * om[1];
-            T = Tk[3];
-#pragma unroll
-            for (int k = 0; k < 4; k++) my_wa[(r0 + k) * WROW + lane] = al[k] * Tk[k];
-        };
-        if constexpr (!GEOM) {
-#pragma unroll
-            for (int r0 = 0; r0 < CHK; r0 += 4) row_group4_w(r0);
-        } else if constexpr (FULL) {  // straight-line code for the full chunk: the 16 rows' LDS reads overlap each other's arithmetic
+        if constexpr (FULL) {  // straight-line code for the full chunk: the 16 rows' LDS reads overlap each other's arithmetic
             if (has_bg) {
 #pragma unroll
                 for (int rr = 0; rr < CHK; rr++) row_step(rr);
@@ -459,7 +420,7 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
             for (int s4 = 0; s4 < 4; s4++) {
                 const float4 wv = wrow[s4];
                 const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
-                const float4 uv = GEOM ? urow[s4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 uv = urow[s4];
                 const float ua[4] = {uv.x, uv.y, uv.z, uv.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -467,11 +428,9 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++)
                         facc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], dLT[nb][s], facc[nb], 0, 0, 0);
-                    if constexpr (GEOM) {
-                        const float x = (float)(s & 7) - 3.5f;
-                        const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
-                        macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
-                    }
+                    const float x = (float)(s & 7) - 3.5f;
+                    const float phi = fmaf(x, fmaf(x, phR, phQ[s >> 3]), phP[s >> 3]);
+                    macc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], phi, macc, 0, 0, 0);
                 }
             }
         }
@@ -497,7 +456,6 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
                 }
             }
         }
-        if constexpr (GEOM) {
         // (a separate, unconditional loop: with the store inside the loop above and guarded by n16 < 8, hipcc clones the
         // atomics into both arms of the guard -- twice the memory instructions, and a count that depends on the path)
 #pragma unroll
@@ -538,7 +496,6 @@ __global__ void __launch_bounds__(64, BwvCfg<C>::WAVES) blend_bwd_wave_kernel(
                 const uint32_t gid2 = __float_as_uint(*reinterpret_cast<const float*>(par_bytes + row2 * (int)sizeof(BwdPar) + 28));
                 if (FULL || row2 < nrows) atomicAdd(&gpack[(size_t)gid2 * 8 + f], my_mom[row2 * MROW + f]);   // fields 6, 7 receive +0
             }
-        }
         }
     };
     // Full chunks: the first one peeled off, the rest in a loop whose every iteration issues the same memory instructions.

@@ -23,6 +23,7 @@
 #include "blend_bwd.h"
 #include "blend_bwd_wave.h"   // (the profiling build compiles the PRODUCT kernel too: what tools/ measure is what ships; the ablation
                               // masks and rejected variants of rounds 2-5 are a record under tools/experiments/, compiled nowhere)
+#include "blend_bwd_feat.h"   // features-only backward, 16- / 32-channel blocks: one wave per half tile
 #include "blend_fwd.h"
 #include "blend_fwd_wave.h"
 #ifdef MI_RAST_PROFILING
@@ -1293,16 +1294,16 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
         } else
 #endif
         if (feat_only) {
-            // one launch per channel block of 64 / 32 / 16 channels, GEOM = false: alpha, T, dF = W^T dL and the feature-row atomics
-#define LAUNCH_BWD_FEAT_(C_, XE, ST)                                                                                             \
-    hipLaunchKernelGGL((blend_bwd_wave_kernel<C_, C_, false, XE, ST, false>), dim3(32u * xcd_static_len_max(nt_) + 4u * xcd_queued_tiles_max(nt_)), \
-                       dim3(64), 0, stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, bg_blk,      \
-                       colors_blk, img.final_T, img.n_contrib, dpix_blk, (const float*)nullptr, geom.bwd_pack, dcolor_blk, queue_ctr, cstride,  \
-                       cr_blk, img.run_bounds)
-#define LAUNCH_BWD_FEAT(C_)                                                                  \
+            // one launch per channel block of 64 / 32 / 16 channels (blend_bwd_feat.h: one wave per half tile): alpha, T, dF = W^T dL and
+            // the feature-row atomics
+#define LAUNCH_BWD_HALF_(C_, XE, ST)                                                                                             \
+    hipLaunchKernelGGL((blend_bwd_feat_kernel<C_, XE, ST>), dim3(16u * xcd_static_len_max(nt_) + 2u * xcd_queued_tiles_max(nt_)), dim3(64), 0,  \
+                       stream, img.ranges, bin.blend_list, geom.index_rec, img.tile_nsurv, vp.W, vp.H, vp.grid_x, nt_, img.final_T,             \
+                       img.n_contrib, dpix_blk, dcolor_blk, queue_ctr, cstride, img.run_bounds)
+#define LAUNCH_BWD_HALF(C_)                                                                  \
     do {                                                                                     \
-        if (cstride == C_) { if (xexp) LAUNCH_BWD_FEAT_(C_, true, false); else LAUNCH_BWD_FEAT_(C_, false, false); } \
-        else { if (xexp) LAUNCH_BWD_FEAT_(C_, true, true); else LAUNCH_BWD_FEAT_(C_, false, true); }                 \
+        if (cstride == C_) { if (xexp) LAUNCH_BWD_HALF_(C_, true, false); else LAUNCH_BWD_HALF_(C_, false, false); } \
+        else { if (xexp) LAUNCH_BWD_HALF_(C_, true, true); else LAUNCH_BWD_HALF_(C_, false, true); }                 \
     } while (0)
             const size_t HW = (size_t)width * height;
             for (int c0 = 0; c0 < channels;) {
@@ -1312,14 +1313,14 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
                 dpix_blk = dL_dpix + (size_t)c0 * HW;
                 dcolor_blk = dL_dcolor + c0;
                 cr_blk = cb;
-                if (cb == 64) LAUNCH_BWD_FEAT(64);
-                else if (cb == 32) LAUNCH_BWD_FEAT(32);
-                else LAUNCH_BWD_FEAT(16);
+                if (cb == 64) LAUNCH_BWD_HALF(64);
+                else if (cb == 32) LAUNCH_BWD_HALF(32);
+                else LAUNCH_BWD_HALF(16);
                 queue_ctr += 8 * XCD_QUEUE_STRIDE;
                 c0 += cb;
             }
-#undef LAUNCH_BWD_FEAT
-#undef LAUNCH_BWD_FEAT_
+#undef LAUNCH_BWD_HALF
+#undef LAUNCH_BWD_HALF_
         } else if (maskgrad) LAUNCH_BWD_WAVE(16, 3, true);
         else if (channels == 3) LAUNCH_BWD_WAVE(16, 3, false);
         else {
