@@ -1,4 +1,5 @@
-"""The features-only backward (EXTENSION, include/mi_rast.h: MI_RAST_BWD_FEATURES_ONLY; seganygaussians_amd/rasterizer.py):
+"""The features-only backward (EXTENSION, include/mi_rast.h: MI_RAST_BWD_FEATURES_ONLY; seganygaussians_amd/rasterizer.py; kernel:
+csrc/blend_bwd_feat.h, one wave per half tile, channel blocks of 64 / 32 / 16):
 dL_dcolors_precomp alone -- automatic when autograd asks for nothing else, opt-in (enable_features_only_backward /
 MI_RAST_FEATURES_ONLY_BACKWARD=1) for callers whose other inputs require grad without anybody reading those gradients
 (SAGA's contrastive feature training, scene/gaussian_model_ff.py:154-162).  Checked against the CPU oracle's dL_dcolors
@@ -79,7 +80,7 @@ def _render_and_backward(C, inp, dev, geometry_grad, dL):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("C,W,H,bg", [(32, 208, 144, None), (32, 200, 136, "random"), (64, 176, 112, None), (48, 160, 96, "random"),
-                                      (16, 96, 80, None)])
+                                      (16, 96, 80, None), (128, 120, 72, None), (80, 104, 88, "random")])
 def test_opt_in_matches_the_default_backward_and_the_oracle(C, W, H, bg):
     """Every input requires grad (the reference's feature training); with the switch on only colors_precomp receives one --
     the one the oracle and the default backward compute."""
