@@ -23,7 +23,7 @@
 #include "blend_bwd.h"
 #include "blend_bwd_wave.h"   // (the profiling build compiles the PRODUCT kernel too: what tools/ measure is what ships; the ablation
                               // masks and rejected variants of rounds 2-5 are a record under tools/experiments/, compiled nowhere)
-#include "blend_bwd_feat.h"   // features-only backward, 16- / 32-channel blocks: one wave per half tile
+#include "blend_bwd_feat.h"   // features-only backward (MI_RAST_BWD_FEATURES_ONLY): one wave per half tile
 #include "blend_fwd.h"
 #include "blend_fwd_wave.h"
 #ifdef MI_RAST_PROFILING
@@ -1244,7 +1244,7 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
     if (!channels_supported(channels)) return fail(MI_RAST_ERR_INVALID, "unsupported channel count (supported: 1 .. 256)");
     const bool maskgrad = dL_dmask != nullptr;
     if (maskgrad && (channels != 3 || !dL_dout_mask)) return fail(MI_RAST_ERR_INVALID, "mask gradient needs 3 channels and dL_dout_mask");
-    // EXTENSION (mi_rast.h): dL_dcolor alone -- the blend kernel in its GEOM = false form, no geometry backward
+    // EXTENSION (mi_rast.h): dL_dcolor alone -- blend_bwd_feat.h instead of the full blend kernel, no geometry backward
     const bool feat_only = (flags & MI_RAST_BWD_FEATURES_ONLY) != 0;
     if (feat_only && (!mi_rast_features_only_supported(channels) || colors_precomp == nullptr || maskgrad || dL_dcolor == nullptr))
         return fail(MI_RAST_ERR_INVALID, "MI_RAST_BWD_FEATURES_ONLY needs colors_precomp, dL_dcolor and a channel count that is a multiple of 16");
@@ -1308,11 +1308,8 @@ int mi_rast_backward(int P, int D, int M, int channels, int R, const float* back
             const size_t HW = (size_t)width * height;
             for (int c0 = 0; c0 < channels;) {
                 const int cb = channel_block(channels - c0);
-                bg_blk = background + c0;
-                colors_blk = color_ptr + c0;
                 dpix_blk = dL_dpix + (size_t)c0 * HW;
                 dcolor_blk = dL_dcolor + c0;
-                cr_blk = cb;
                 if (cb == 64) LAUNCH_BWD_HALF(64);
                 else if (cb == 32) LAUNCH_BWD_HALF(32);
                 else LAUNCH_BWD_HALF(16);
