@@ -149,3 +149,25 @@ def test_c_abi_refuses_what_the_form_does_not_serve():
                             None, None, None, None, None, None, None, None, None, None, 0, _lib.MI_RAST_BWD_FEATURES_ONLY, None)
     assert rc == 1
     assert b"MI_RAST_BWD_FEATURES_ONLY" in L.mi_rast_last_error()
+
+
+@pytest.mark.gpu
+def test_bench_reports_both_opt_ins_as_separately_labelled_objects():
+    """bench.py --features-only-grad --frozen-geometry: the headline fields are there as always, the two opt-ins appear as objects of
+    their own (never in `value`), the features-only gradient equals the default backward's, the other leaves stay without gradients."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--points", "150000", "--no-cpu-baseline",
+                          "--settle", "0", "--dist-blocks", "0", "--sustained-seconds", "0", "--features-only-grad", "--frozen-geometry",
+                          "--views", "3", "--frozen-passes", "2"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["value"] > 0 and line["config"]["counters"]["P"] == 150000 and "geom_bwd" in line["config"]["stages_ms"]
+    fo, fg = line["features_only_backward"], line["frozen_geometry"]
+    assert fo["other_gradients_unset"] is True and fo["views_per_s"] > 0 and "geom_bwd" not in fo["stages_ms"]
+    assert fo["dL_dfeatures_max_abs_diff_vs_default"] <= 2e-5 * fo["dL_dfeatures_max_abs"]
+    assert fo["views_per_s_with_frozen_geometry_all_hits"] > 0
+    assert fg["hits"] >= 3 and fg["views_per_s"] > 0
