@@ -138,7 +138,8 @@ class GpuRun:
             self.out_mask = self.out_depth = None
         return self
 
-    def backward(self, dL_dout_color, dL_dout_mask=None, debug=False, prezeroed=None):
+    def backward(self, dL_dout_color, dL_dout_mask=None, debug=False, prezeroed=None, features_only=False):
+        """features_only (include/mi_rast.h: MI_RAST_BWD_FEATURES_ONLY): returns {"dL_dcolors": ...} alone."""
         i, torch = self.inp, self.torch
         g = torch.as_tensor(np.ascontiguousarray(dL_dout_color, np.float32)).to(self.dev)
         gm = None
@@ -149,7 +150,10 @@ class GpuRun:
         res = self.R.rasterize_gaussians_backward_native(
             i.channels, self.with_mask, self.bg, self.means3D, self.radii, self.colors, self.scales, self.rots,
             i.scale_modifier, self.cov, self.view, self.proj, i.tanfovx, i.tanfovy, g, gm, self.shs, i.sh_degree,
-            self.campos, self.geom, self.num_rendered, self.binning, self.img, debug, prezeroed=prezeroed)
+            self.campos, self.geom, self.num_rendered, self.binning, self.img, debug, prezeroed=prezeroed, features_only=features_only)
+        if features_only:
+            assert all(v is None for k_, v in enumerate(res) if k_ != 1)
+            return {"dL_dcolors": res[1].detach().cpu().numpy()}
         names = (["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmask", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
                   "dL_dscales", "dL_drotations"] if self.with_mask else
                  ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",

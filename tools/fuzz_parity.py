@@ -59,6 +59,12 @@ def one_case(rng, k, run=True, diagnose=False):
     bwd = so.backward(inp, fwd, dL, None if dLm is None else dLm[0])
     hp.compare_gradients(grads, bwd)
     hp.compare_lean_with_full(inp, gpu, dL, dLm, grads)   # the product default: identical blend lists and images
+    if C % 16 == 0 and not with_shs and not use_mask:   # the features-only backward (csrc/blend_bwd_feat.h) against the default one's dL_dcolors
+        fo = gpu.backward(dL, None, features_only=True)["dL_dcolors"]
+        ref_ = grads["dL_dcolors"]
+        err, scale = float(np.abs(fo - ref_).max()), float(np.abs(ref_).max())
+        assert err <= 2e-5 * scale, f"features-only dL_dcolors off by {err:.3g} of {scale:.3g}"
+        hp.assert_close("features-only dL_dcolors", fo, bwd.dL_dcolors, flip_frac=hp.GRAD_FLIP_FRAC)
     return desc, fwd.num_rendered
 
 
